@@ -1,0 +1,114 @@
+"""CPU restatement of src/geo/kmeans_optimized.py (reference).  TEST INFRASTRUCTURE ONLY.
+
+Two drivers are given: `fit_kmedoids_optimized` follows the reference's three stages literally
+(3K-1 shortest-path solves), `fit_kmedoids_single_pass` is the K-solve formulation the HIP path
+uses (running min / first-argmin during seeding); tests assert they agree bit for bit.
+"""
+from typing import List
+
+import numpy as np
+
+from .sssp import dijkstra_multi_source, dijkstra_single_source
+
+
+def _seeding_probs(d_min: np.ndarray, centers: List[int]) -> np.ndarray:
+    """kmeans_optimized.py:47-57: float32 D^2 weights with the inf -> 2*max_finite substitution."""
+    finite = np.isfinite(d_min)
+    if finite.any():
+        safe = np.where(finite, d_min, np.max(d_min[finite]) * 2.0)
+    else:
+        safe = np.ones_like(d_min)
+    probs = safe ** 2
+    probs[centers] = 0.0
+    return probs
+
+
+def _draw_next(rng, N: int, probs: np.ndarray, centers: List[int]):
+    """kmeans_optimized.py:59-69.  Returns None when no candidate is left."""
+    total = probs.sum()
+    if total > 0:
+        probs /= total
+        return int(rng.choice(N, p=probs))
+    rest = [i for i in range(N) if i not in centers]
+    if rest:
+        return int(rng.choice(rest))
+    return None
+
+
+def kpp_initialization_graph(W, K: int, seed: int = 42) -> List[int]:
+    """kmeans_optimized.py:14-74."""
+    N = W.shape[0]
+    rng = np.random.RandomState(seed)
+    centers = [int(rng.randint(0, N))]
+    d_min = np.full(N, np.inf, dtype=np.float32)
+    for _ in range(1, K):
+        d_min = np.minimum(d_min, dijkstra_single_source(W, centers[-1], dtype=np.float32))
+        nxt = _draw_next(rng, N, _seeding_probs(d_min, centers), centers)
+        if nxt is None:
+            break
+        centers.append(nxt)
+    return centers
+
+
+def assign_points_to_medoids(W, medoids) -> np.ndarray:
+    """kmeans_optimized.py:77-106."""
+    D = dijkstra_multi_source(W, medoids, dtype=np.float32)
+    return D.argmin(axis=0).astype(int)
+
+
+def quantization_error_from(dist_to_assigned: np.ndarray) -> float:
+    """kmeans_optimized.py:131-136: float32 squares, numpy sum over the finite ones."""
+    finite = np.isfinite(dist_to_assigned)
+    if finite.any():
+        return float(np.sum(dist_to_assigned[finite] ** 2))
+    return float("inf")
+
+
+def compute_quantization_error(W, medoids, assign) -> float:
+    """kmeans_optimized.py:109-138."""
+    D = dijkstra_multi_source(W, medoids, dtype=np.float32)
+    return quantization_error_from(D[assign, np.arange(len(assign))])
+
+
+def _init_medoids(W, K, init, seed):
+    if init == "kpp":
+        return np.array(kpp_initialization_graph(W, K, seed=seed), dtype=int)
+    if init == "random":
+        rng = np.random.RandomState(seed)
+        return rng.choice(W.shape[0], size=min(K, W.shape[0]), replace=False).astype(int)
+    raise ValueError("init must be 'kpp' or 'random'")
+
+
+def fit_kmedoids_optimized(W, K: int = 512, init: str = "kpp", seed: int = 42):
+    """kmeans_optimized.py:141-183, stage by stage."""
+    medoids = _init_medoids(W, K, init, seed)
+    assign = assign_points_to_medoids(W, medoids)
+    qe = compute_quantization_error(W, medoids, assign)
+    return medoids, assign, qe
+
+
+def fit_kmedoids_single_pass(W, K: int = 512, seed: int = 42):
+    """Same outputs as fit_kmedoids_optimized(init='kpp') from K solves instead of 3K-1."""
+    N = W.shape[0]
+    rng = np.random.RandomState(seed)
+    centers = [int(rng.randint(0, N))]
+    d_min = np.full(N, np.inf, dtype=np.float32)
+    arg = np.zeros(N, dtype=int)
+
+    def absorb(pos):
+        nonlocal d_min
+        d = dijkstra_single_source(W, centers[pos], dtype=np.float32)
+        better = d < d_min                      # strict: the first minimal row index wins
+        arg[better] = pos
+        d_min = np.where(better, d, d_min)
+
+    for _ in range(1, K):
+        absorb(len(centers) - 1)
+        nxt = _draw_next(rng, N, _seeding_probs(d_min, centers), centers)
+        if nxt is None:
+            break
+        centers.append(nxt)
+    else:
+        absorb(len(centers) - 1)                # the last centre gets no solve inside k++
+    # (after an early break every listed centre has already been absorbed)
+    return np.array(centers, dtype=int), arg, quantization_error_from(d_min)

@@ -1,0 +1,131 @@
+"""CPU restatement of src/geo/knn_graph_optimized.py (reference).  TEST INFRASTRUCTURE ONLY.
+
+The neighbour search (sklearn in the reference, knn_graph_optimized.py:40-42) is restated as an exact
+fp64-ranked brute force in geo_oracle.c; the CSR assembly / symmetrisation (:54-66) with plain numpy
+key arithmetic; connected components (:173-181) with a scan-order flood fill.
+"""
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+from scipy import sparse
+
+from ._clib import lib
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def knn_search(z: np.ndarray, n_neighbors: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(distances fp64 (N,kq), indices int64 (N,kq)) including self, sorted by (distance, index).
+
+    sklearn's algorithm="auto" picks the kd-tree for d <= 15 and brute force above
+    (sklearn/neighbors/_base.py:627): the squared distance is formed directly for the former and by
+    the |x|^2 - 2xy + |y|^2 expansion for the latter.
+    """
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    N, d = z.shape
+    idx = np.empty((N, n_neighbors), np.int64)
+    d2 = np.empty((N, n_neighbors), np.float64)
+    form = 1 if d > 15 else 0
+    rc = lib().oracle_knn(_ptr(z), N, d, n_neighbors, form, 0, N, _ptr(idx), _ptr(d2))
+    if rc != 0:
+        raise RuntimeError(f"oracle_knn failed: {rc}")
+    return np.sqrt(d2), idx
+
+
+def drop_self(distances: np.ndarray, indices: np.ndarray):
+    """knn_graph_optimized.py:45-52: drop column 0 when it is self everywhere, else each row's first minimum."""
+    N = indices.shape[0]
+    if (indices[:, 0] == np.arange(N)).all():
+        return distances[:, 1:], indices[:, 1:]
+    pos = np.argmin(distances, axis=1)
+    keep = np.ones(distances.shape, dtype=bool)
+    keep[np.arange(N), pos] = False
+    return distances[keep].reshape(N, -1), indices[keep].reshape(N, -1)
+
+
+def symmetrise(N: int, indices: np.ndarray, weights: np.ndarray, sym: str) -> sparse.csr_matrix:
+    """Directed kNN lists -> canonical symmetric CSR (f32), zero diagonal, no stored zeros (:54-66)."""
+    if sym not in ("mutual", "union"):
+        raise ValueError(f"Invalid symmetry mode: {sym}")
+    rows = np.repeat(np.arange(N, dtype=np.int64), indices.shape[1])
+    cols = indices.ravel().astype(np.int64)
+    w = weights.ravel().astype(np.float32)
+    fwd = rows * N + cols
+    bwd = cols * N + rows
+    keys = np.union1d(fwd, bwd)
+    a = np.zeros(keys.shape[0], np.float32)          # W[r, c], absent = 0
+    b = np.zeros(keys.shape[0], np.float32)          # W[c, r]
+    a[np.searchsorted(keys, fwd)] = w
+    b[np.searchsorted(keys, bwd)] = w
+    val = np.maximum(a, b) if sym == "union" else np.minimum(a, b)
+    r, c = keys // N, keys % N
+    keep = (r != c) & (val != 0)
+    return sparse.csr_matrix((val[keep], (r[keep], c[keep])), shape=(N, N), dtype=np.float32)
+
+
+def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
+                            sym: str = "mutual") -> Tuple[sparse.csr_matrix, Dict[str, np.ndarray]]:
+    assert z.ndim == 2, "z must be (N,D)"
+    if metric != "euclidean":
+        raise NotImplementedError("oracle restates the euclidean metric only")
+    N = z.shape[0]
+    if N == 0:
+        return (sparse.csr_matrix((0, 0), dtype=np.float32),
+                {"distances": np.empty((0, 0), np.float32), "indices": np.empty((0, 0), dtype=int)})
+    k_eff = max(0, min(k, N - 1))
+    if k_eff == 0:
+        return (sparse.csr_matrix((N, N), dtype=np.float32),
+                {"distances": np.empty((N, 0), np.float32), "indices": np.empty((N, 0), dtype=int)})
+    dist, idx = knn_search(z, min(k_eff + 1, N))
+    dist, idx = drop_self(dist, idx)
+    weights = dist if mode == "distance" else np.ones_like(dist)
+    W = symmetrise(N, idx, weights, sym)
+    return W, {"distances": dist.astype(np.float32), "indices": idx}
+
+
+def build_knn_graph_auto(z, k=10, metric="euclidean", mode="distance", sym="mutual",
+                         force_method: Optional[str] = None, size_threshold: int = 50000):
+    if force_method == "faiss":
+        raise RuntimeError("force_method='faiss' but FAISS not available")
+    return build_knn_graph_sklearn(z, k=k, metric=metric, mode=mode, sym=sym)
+
+
+def build_knn_graph(z, k=10, metric="euclidean", mode="distance", sym="mutual"):
+    return build_knn_graph_auto(z, k=k, metric=metric, mode=mode, sym=sym)
+
+
+def connected_components(W: sparse.spmatrix) -> Tuple[int, np.ndarray]:
+    W = sparse.csr_matrix(W)
+    WT = W.T.tocsr()
+    n = W.shape[0]
+    labels = np.empty(n, np.int32)
+    ip, ix = W.indptr.astype(np.int32), W.indices.astype(np.int32)
+    ipT, ixT = WT.indptr.astype(np.int32), WT.indices.astype(np.int32)
+    ncomp = lib().oracle_cc(n, _ptr(ip), _ptr(ix), _ptr(ipT), _ptr(ixT), _ptr(labels))
+    return int(ncomp), labels
+
+
+def largest_connected_component(W: sparse.spmatrix) -> np.ndarray:
+    """knn_graph_optimized.py:173-181."""
+    ncomp, labels = connected_components(W)
+    if ncomp <= 1:
+        return np.ones(W.shape[0], dtype=bool)
+    return labels == np.argmax(np.bincount(labels))
+
+
+def analyze_graph_connectivity(W: sparse.spmatrix) -> Dict:
+    """knn_graph_optimized.py:184-219 (stats only, no prints)."""
+    N = W.shape[0]
+    ncomp, labels = connected_components(W)
+    if ncomp > 1:
+        largest = int(np.bincount(labels).max())
+        ratio = largest / N
+    else:
+        largest, ratio = N, 1.0
+    deg = np.asarray(W.sum(axis=1)).ravel()
+    return {"n_nodes": N, "n_edges": W.nnz, "n_components": ncomp, "largest_component_size": largest,
+            "connectivity_ratio": ratio, "avg_degree": deg.mean(), "min_degree": deg.min(),
+            "max_degree": deg.max()}

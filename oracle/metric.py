@@ -1,0 +1,145 @@
+"""CPU restatement of src/geo/riemannian_metric.py over src/models/spatial_vae.py:47-81 (reference).
+TEST INFRASTRUCTURE ONLY.
+
+The reference obtains J(z)·δ by the double-backward trick of torch.autograd.functional.jvp
+(riemannian_metric.py:32).  This file states the same quantity in closed form: the tangent is
+pushed forward layer by layer next to the primal (forward-mode), for the SpatialDecoder layer
+sequence  conv1x1 -> [ConvT(k4,s2,p1) -> norm -> ReLU] x2 -> ConvT(k4,s2,p=3|1) -> sigmoid.
+
+The decoder is described by its state_dict (the reference's key names: "conv_in.weight",
+"deconv_layers.{0,3,6}.weight/bias", "deconv_layers.{1,4}.weight/bias/running_mean/running_var"),
+the norm type and the output image size -- no nn.Module is needed.
+"""
+from typing import Mapping
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+GN_EPS = 1e-5
+
+
+def group_count(channels: int) -> int:
+    """spatial_vae.py:13-16."""
+    g = max(1, min(32, channels))
+    while channels % g != 0 and g > 1:
+        g -= 1
+    return g
+
+
+def _t(sd: Mapping, key: str, dtype):
+    v = sd[key]
+    if not torch.is_tensor(v):
+        v = torch.from_numpy(np.asarray(v))
+    return v.detach().to("cpu", dtype)
+
+
+def _norm_push(x, t, sd, prefix, norm_type, training, dtype):
+    """Primal and tangent through one normalisation layer."""
+    if norm_type == "none":
+        return x, t
+    gamma = _t(sd, prefix + ".weight", dtype).view(1, -1, 1, 1)
+    beta = _t(sd, prefix + ".bias", dtype).view(1, -1, 1, 1)
+    if norm_type == "batch" and not training:
+        rm = _t(sd, prefix + ".running_mean", dtype).view(1, -1, 1, 1)
+        rv = _t(sd, prefix + ".running_var", dtype).view(1, -1, 1, 1)
+        inv = 1.0 / torch.sqrt(rv + BN_EPS)
+        return (x - rm) * inv * gamma + beta, t * inv * gamma
+    if norm_type == "batch":
+        dims, eps = (0, 2, 3), BN_EPS
+        xs, ts = x, t
+    elif norm_type == "group":
+        B, C, H, Wd = x.shape
+        g = group_count(C)
+        xs, ts = x.reshape(B, g, -1), t.reshape(B, g, -1)
+        dims, eps = (2,), GN_EPS
+    else:
+        raise ValueError(norm_type)
+    mu = xs.mean(dim=dims, keepdim=True)
+    var = ((xs - mu) ** 2).mean(dim=dims, keepdim=True)          # biased, as torch normalises
+    inv = 1.0 / torch.sqrt(var + eps)
+    xhat = (xs - mu) * inv
+    that = inv * (ts - ts.mean(dim=dims, keepdim=True) - xhat * (xhat * ts).mean(dim=dims, keepdim=True))
+    xhat, that = xhat.reshape(x.shape), that.reshape(x.shape)
+    return xhat * gamma + beta, that * gamma
+
+
+def jvp_norms(sd: Mapping, norm_type: str, output_image_size: int, z, delta, training: bool,
+              dtype=torch.float32) -> torch.Tensor:
+    """|| d/de sigmoid(decoder(z + e*delta)) ||_2 per row, for one batch (BN statistics are taken over it)."""
+    norm_type = (norm_type or "none").lower()
+    if norm_type not in ("batch", "group"):
+        norm_type = "none"
+    pad_last = {28: 3, 32: 1}[int(output_image_size)]
+    z = torch.as_tensor(z).to(dtype)
+    delta = torch.as_tensor(delta).to(dtype)
+    x = z.view(z.shape[0], -1, 1, 1)
+    t = delta.view(delta.shape[0], -1, 1, 1)
+    w = _t(sd, "conv_in.weight", dtype)
+    x = F.conv2d(x, w, _t(sd, "conv_in.bias", dtype))
+    t = F.conv2d(t, w)
+    for conv, norm in ((0, 1), (3, 4)):
+        w = _t(sd, f"deconv_layers.{conv}.weight", dtype)
+        x = F.conv_transpose2d(x, w, _t(sd, f"deconv_layers.{conv}.bias", dtype), stride=2, padding=1)
+        t = F.conv_transpose2d(t, w, None, stride=2, padding=1)
+        x, t = _norm_push(x, t, sd, f"deconv_layers.{norm}", norm_type, training, dtype)
+        t = t * (x > 0).to(dtype)
+        x = torch.relu(x)
+    w = _t(sd, "deconv_layers.6.weight", dtype)
+    x = F.conv_transpose2d(x, w, _t(sd, "deconv_layers.6.bias", dtype), stride=2, padding=pad_last)
+    t = F.conv_transpose2d(t, w, None, stride=2, padding=pad_last)
+    s = torch.sigmoid(x)
+    jt = (t * s * (1.0 - s)).reshape(z.shape[0], -1)
+    return torch.linalg.vector_norm(jt, dim=1)
+
+
+def edge_lengths(sd: Mapping, norm_type: str, output_image_size: int, z_start, z_end, batch_size: int = 512,
+                 training: bool = True, dtype=torch.float32) -> torch.Tensor:
+    """riemannian_metric.py:37-66: 0.5*(|J(z_i)δ| + |J(z_j)δ|), chunked exactly like the reference."""
+    z_start = torch.as_tensor(z_start).to(dtype)
+    z_end = torch.as_tensor(z_end).to(dtype)
+    assert z_start.shape == z_end.shape, "Start and end points must have same shape"
+    delta = z_end - z_start
+    out = []
+    with torch.no_grad():
+        for lo in range(0, z_start.shape[0], batch_size):
+            hi = min(lo + batch_size, z_start.shape[0])
+            a = jvp_norms(sd, norm_type, output_image_size, z_start[lo:hi], delta[lo:hi], training, dtype)
+            b = jvp_norms(sd, norm_type, output_image_size, z_end[lo:hi], delta[lo:hi], training, dtype)
+            out.append(0.5 * (a + b))
+    if not out:
+        return torch.empty(0, dtype=torch.float32)
+    return torch.cat(out).to(torch.float32)
+
+
+def make_decoder_state(seed: int, latent_dim: int, out_channels: int, channels=(256, 128, 64),
+                       norm_type: str = "batch") -> dict:
+    """Seeded synthetic SpatialDecoder weights (golden fixture G3): numpy RandomState, so the same
+    state_dict can be regenerated on the GPU box without shipping megabytes of weights."""
+    r = np.random.RandomState(seed)
+    c0, c1, c2 = channels
+
+    def u(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return r.uniform(-b, b, size=shape).astype(np.float32)
+
+    sd = {
+        "conv_in.weight": u((c0, latent_dim, 1, 1), latent_dim),
+        "conv_in.bias": u((c0,), latent_dim),
+        "deconv_layers.0.weight": u((c0, c1, 4, 4), c1 * 16),
+        "deconv_layers.0.bias": u((c1,), c1 * 16),
+        "deconv_layers.3.weight": u((c1, c2, 4, 4), c2 * 16),
+        "deconv_layers.3.bias": u((c2,), c2 * 16),
+        "deconv_layers.6.weight": u((c2, out_channels, 4, 4), out_channels * 16),
+        "deconv_layers.6.bias": u((out_channels,), out_channels * 16),
+    }
+    if norm_type in ("batch", "group"):
+        for idx, c in ((1, c1), (4, c2)):
+            sd[f"deconv_layers.{idx}.weight"] = r.uniform(0.5, 1.5, size=c).astype(np.float32)
+            sd[f"deconv_layers.{idx}.bias"] = r.uniform(-0.3, 0.3, size=c).astype(np.float32)
+            if norm_type == "batch":
+                sd[f"deconv_layers.{idx}.running_mean"] = r.uniform(-0.2, 0.2, size=c).astype(np.float32)
+                sd[f"deconv_layers.{idx}.running_var"] = r.uniform(0.5, 1.5, size=c).astype(np.float32)
+                sd[f"deconv_layers.{idx}.num_batches_tracked"] = np.array(0, dtype=np.int64)
+    return sd

@@ -1,0 +1,70 @@
+"""CPU restatement of src/scripts/build_codebook.py:14-106 (reference) on in-memory arrays.
+TEST INFRASTRUCTURE ONLY.  Stage timers are kept so bench.py can report the CPU baseline per stage.
+"""
+import time
+from typing import Mapping
+
+import numpy as np
+from scipy import sparse
+
+from . import kmedoids, knn, metric
+
+
+def flatten_latents(z4: np.ndarray) -> np.ndarray:
+    """(N,C,H,W) -> (N*H*W, C), row = (n,h,w)  (build_codebook.py:35)."""
+    N, C, H, W = z4.shape
+    return np.ascontiguousarray(np.transpose(z4, (0, 2, 3, 1)).reshape(-1, C))
+
+
+def upper_edges(W: sparse.csr_matrix) -> np.ndarray:
+    """Row-major list of stored entries with row < col (build_codebook.py:43-45)."""
+    W = sparse.csr_matrix(W)
+    rows = np.repeat(np.arange(W.shape[0]), np.diff(W.indptr))
+    cols = W.indices
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    keep = rows < cols
+    return np.stack((rows[keep], cols[keep]), axis=1)
+
+
+def reweighted_graph(N: int, edges: np.ndarray, lengths: np.ndarray) -> sparse.csr_matrix:
+    """W_geo = U + U^T; entries that sum to exactly 0 vanish (build_codebook.py:53-54)."""
+    U = sparse.csr_matrix((lengths.astype(np.float32), (edges[:, 0], edges[:, 1])), shape=(N, N))
+    return U + U.T
+
+
+def build_codebook(z4: np.ndarray, decoder_sd: Mapping, norm_type: str, output_image_size: int,
+                   k: int = 20, sym: str = "union", K: int = 512, init: str = "kpp", seed: int = 42,
+                   batch_size: int = 512, training: bool = True, timers: dict = None) -> dict:
+    t = timers if timers is not None else {}
+    N, C, H, Wd = z4.shape
+    z_flat = flatten_latents(z4.astype(np.float32))
+
+    t0 = time.perf_counter()
+    W_e, _ = knn.build_knn_graph_auto(z_flat, k=k, metric="euclidean", mode="connectivity", sym=sym)
+    edges = upper_edges(W_e)
+    t["knn"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    lengths = metric.edge_lengths(decoder_sd, norm_type, output_image_size, z_flat[edges[:, 0]],
+                                  z_flat[edges[:, 1]], batch_size=batch_size, training=training).numpy()
+    t["jvp"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    W_geo = reweighted_graph(z_flat.shape[0], edges, lengths)
+    mask = knn.largest_connected_component(W_geo)
+    if mask.sum() < W_geo.shape[0]:
+        W_lcc, z_lcc = W_geo[mask][:, mask], z_flat[mask]
+    else:
+        W_lcc, z_lcc = W_geo, z_flat
+    t["lcc"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    medoids, assign, qe = kmedoids.fit_kmedoids_optimized(W_lcc, K=K, init=init, seed=seed)
+    t["kmedoids"] = time.perf_counter() - t0
+
+    codes = np.full(z_flat.shape[0], -1, dtype=np.int32)
+    codes[mask] = assign
+    return {"codes": codes.reshape(N, H, Wd), "medoid_indices": medoids.astype(np.int32),
+            "z_medoid": z_lcc[medoids].astype(np.float32), "W_lcc": sparse.csr_matrix(W_lcc),
+            "mask_lcc": mask, "qe": qe, "edges": edges, "edge_lengths": lengths}
