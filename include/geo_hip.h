@@ -1,0 +1,180 @@
+/*
+ * geo_hip.h -- C ABI of libgeo_hip.so, the MI355X (gfx950) implementation of the geodesic-codebook
+ * hot path of m4rch1n0/vqvae (src/geo + src/scripts/build_codebook.py).
+ *
+ * The reference has no FFI boundary of its own: its boundary is the Python API of src/geo, whose
+ * numerics are executed by scipy / scikit-learn / torch.autograd on the CPU.  Each entry point below
+ * replaces one of those third-party call sites (cited as reference file:line) and is what a binding
+ * in the reference's src/geo modules would call (see INTEGRATION.md for the ctypes stubs).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer unless the parameter is marked [host];
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it.  Functions marked
+ *     "synchronises" call hipStreamSynchronize(stream) before returning (they need a host decision);
+ *   - no allocation crosses the ABI: the caller owns inputs, outputs and the workspace `ws`
+ *     (size from the matching *_workspace_bytes query, any 256-byte aligned device buffer);
+ *   - return value: 0 = ok, negative = error (GEO_E_*); geo_last_error() gives the text;
+ *   - thread-compatible, not thread-safe (one call at a time per process).
+ */
+#ifndef GEO_HIP_H
+#define GEO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEO_OK 0
+#define GEO_E_ARG (-1)      /* invalid argument (shape, null pointer, unsupported size) */
+#define GEO_E_WORKSPACE (-2) /* workspace too small */
+#define GEO_E_HIP (-3)      /* a HIP runtime call failed */
+#define GEO_E_NOCONV (-4)   /* iteration limit reached without convergence */
+
+int geo_version(void);
+const char *geo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Shortest paths.  Replaces scipy.sparse.csgraph.dijkstra as called from
+ * src/geo/geo_shortest_paths.py:36-49 (dijkstra_multi_source) and, through it,
+ * src/geo/kmeans_optimized.py:43,97,125.
+ *
+ * The graph is a "pull" CSR: row v lists the nodes u with an edge u->v and its weight.  For an
+ * undirected solve on a symmetric matrix that is the matrix itself.  Path sums are accumulated in
+ * fp64 source-outward, one rounding per hop, and the label-correcting iteration is run to its fixed
+ * point, so the fp64 distances equal Dijkstra's; they are rounded to f32 on output exactly like
+ * geo_shortest_paths.py:50.  weights == NULL means unit weights (unweighted=True, :32-34).
+ * Unreachable = +inf; predecessor sentinel -9999.
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources);
+
+/* S sources -> any of: D_out f32 [S][n]; P_out i32 [S][n]; dmin_out f32 [n] + argmin_out i32 [n]
+ * (column minimum over the S rows of the f32 matrix and the FIRST row index attaining it,
+ * = D.argmin(axis=0) of kmeans_optimized.py:100; all-inf column -> 0).  Any output may be NULL.
+ * sweeps_out [host, may be NULL] receives the number of relaxation sweeps launched.
+ * Synchronises. */
+int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights,
+                   int32_t n, const int32_t *sources, int32_t n_sources,
+                   float *D_out, int32_t *P_out, float *dmin_out, int32_t *argmin_out,
+                   void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
+
+/* One source; fused k-means++ bookkeeping of kmeans_optimized.py:43-44 and the single-pass
+ * assignment: d32 = f32(dist(source, .)); where d32 < dmin: dmin = d32, argmin = center_pos.
+ * d_out f32 [n] may be NULL, dmin_inout/argmin_inout may be NULL.  Synchronises. */
+int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const float *weights,
+                           int32_t n, int32_t source, float *d_out,
+                           float *dmin_inout, int32_t *argmin_inout, int32_t center_pos,
+                           void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * kNN search.  Replaces sklearn NearestNeighbors.kneighbors as called from
+ * src/geo/knn_graph_optimized.py:40-42: exact n_neighbors nearest corpus rows (self included) of the
+ * query rows [row0,row1) of z, ranked on fp64 squared distances, ties ordered by index.
+ * form = 1: |x|^2 - 2 x.y + |y|^2 clamped at 0 (sklearn brute force, d > 15); form = 0: sum of squared
+ * differences (sklearn kd-tree, d <= 15).  idx_out i32 [rows][n_neighbors], d2_out f64 likewise,
+ * both sorted ascending.  n_neighbors <= 64, d <= 128.
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_knn_workspace_bytes(int64_t n, int32_t d);
+int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neighbors, int32_t form,
+                 int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out,
+                 void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Symmetrisation.  Replaces csr_matrix(...) + W.maximum/minimum(W.T) + setdiag(0) +
+ * eliminate_zeros() of src/geo/knn_graph_optimized.py:54-66.
+ * nbr_idx i32 [n][k] / nbr_w f32 [n][k] (NULL = connectivity, all ones) are the directed lists.
+ * mode 0 = union (max), 1 = mutual (min).  Output is canonical CSR (columns ascending, no diagonal,
+ * no stored zeros).  Two calls: geo_symmetrize_count fills indptr_out [n+1] and returns nnz through
+ * nnz_out [host] (synchronises); the caller allocates indices/data and calls geo_symmetrize_fill
+ * with the same workspace (its contents carry over).
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_symmetrize_workspace_bytes(int32_t n, int32_t k);
+int geo_symmetrize_count(const int32_t *nbr_idx, const float *nbr_w, int32_t n, int32_t k, int32_t mode,
+                         int32_t *indptr_out, int64_t *nnz_out, void *ws, size_t ws_bytes, void *stream);
+int geo_symmetrize_fill(const int32_t *nbr_idx, const float *nbr_w, int32_t n, int32_t k, int32_t mode,
+                        const int32_t *indptr, int32_t *indices_out, float *data_out,
+                        void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Upper-triangle edge list in row-major order.  Replaces W.nonzero() + rows<cols of
+ * src/scripts/build_codebook.py:43-45.  upper_ptr_out i32 [n+1] = exclusive count of entries with
+ * col > row; n_edges through [host] pointer (synchronises).  geo_upper_edges_fill writes
+ * src/dst i32 [E] and entry_edge i32 [nnz]: for every stored entry the index of its undirected
+ * edge (so that W_geo = U + U^T of build_codebook.py:53-54 is a gather).
+ * ------------------------------------------------------------------------------------------ */
+int geo_upper_edges_count(const int32_t *indptr, const int32_t *indices, int32_t n,
+                          int32_t *upper_ptr_out, int64_t *n_edges_out, void *ws, size_t ws_bytes, void *stream);
+int geo_upper_edges_fill(const int32_t *indptr, const int32_t *indices, int32_t n, const int32_t *upper_ptr,
+                         int32_t *src_out, int32_t *dst_out, int32_t *entry_edge_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Connected components.  Replaces scipy.sparse.csgraph.connected_components(directed=False) of
+ * src/geo/knn_graph_optimized.py:175,187 for a structurally symmetric CSR.
+ * labels_out i32 [n]: component numbers in order of each component's lowest node (scipy's order).
+ * n_components through [host] pointer.  Synchronises.
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_cc_workspace_bytes(int32_t n);
+int geo_connected_components(const int32_t *indptr, const int32_t *indices, int32_t n,
+                             int32_t *labels_out, int32_t *n_components_out,
+                             void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CSR filtering / compaction.  Replaces the scipy.sparse arithmetic of build_codebook.py:53-54
+ * (entries that sum to exactly zero vanish) and the LCC sub-matrix W[mask][:, mask] (:59).
+ * keep_node u8 [n] (NULL = all) selects rows/columns, entries with weight == 0 are dropped when
+ * drop_zero != 0.  new_index_out i32 [n] = position of each kept node (-1 otherwise).
+ * Two calls like symmetrize (count synchronises).
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_csr_compact_workspace_bytes(int32_t n);
+int geo_csr_compact_count(const int32_t *indptr, const int32_t *indices, const float *data, int32_t n,
+                          const uint8_t *keep_node, int32_t drop_zero, int32_t *new_index_out,
+                          int32_t *indptr_out, int32_t *n_out, int64_t *nnz_out,
+                          void *ws, size_t ws_bytes, void *stream);
+int geo_csr_compact_fill(const int32_t *indptr, const int32_t *indices, const float *data, int32_t n,
+                         const uint8_t *keep_node, int32_t drop_zero, const int32_t *new_index,
+                         const int32_t *indptr_new, int32_t *indices_out, float *data_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder pull-back edge lengths.  Replaces torch.autograd.functional.jvp through SpatialDecoder
+ * (src/geo/riemannian_metric.py:12-35,37-66; src/models/spatial_vae.py:47-81):
+ *   len[e] = 0.5 * ( |J(z[src[e]]) dz| + |J(z[dst[e]]) dz| ),  dz = z[dst[e]] - z[src[e]],
+ * J = Jacobian of sigmoid(decoder(.)) at a 1x1 latent, edges processed in chunks of `batch_size`
+ * consecutive edges (each endpoint side of a chunk is one BatchNorm batch when bn_train != 0).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct geo_decoder_desc {
+    int32_t latent_dim;        /* d */
+    int32_t c0, c1, c2;        /* dec_channels */
+    int32_t out_channels;      /* image channels */
+    int32_t out_size;          /* 28 or 32 */
+    int32_t norm;              /* 0 none, 1 batch, 2 group */
+    int32_t bn_train;          /* batch statistics (decoder.training) */
+    int32_t groups1, groups2;  /* GroupNorm group counts */
+    float eps;
+    /* device pointers, f32, torch layouts */
+    const float *w_in, *b_in;              /* conv_in.weight [c0][d], bias [c0] */
+    const float *w1, *b1;                  /* deconv_layers.0 weight [c0][c1][4][4], bias [c1] */
+    const float *g1, *be1, *rm1, *rv1;     /* deconv_layers.1 (norm) weight, bias, running_mean, running_var */
+    const float *w2, *b2;                  /* deconv_layers.3 weight [c1][c2][4][4], bias [c2] */
+    const float *g2, *be2, *rm2, *rv2;     /* deconv_layers.4 */
+    const float *w3, *b3;                  /* deconv_layers.6 weight [c2][out_channels][4][4], bias */
+} geo_decoder_desc;
+
+size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size);
+int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes,
+                          const int32_t *src, const int32_t *dst, int64_t n_edges, int32_t batch_size,
+                          float *len_out, void *ws, size_t ws_bytes, void *stream);
+
+/* Same quantity for explicit endpoint arrays (edge_lengths_riemannian's own signature):
+ * z_start / z_end f32 [E][d]. */
+int geo_decoder_jvp_pairs(const geo_decoder_desc *dec, const float *z_start, const float *z_end,
+                          int64_t n_edges, int32_t batch_size, float *len_out,
+                          void *ws, size_t ws_bytes, void *stream);
+
+/* Gather: data_out[e] = len[entry_edge[e]] for every stored entry (W_geo = U + U^T). */
+int geo_gather_edge_weights(const float *len, const int32_t *entry_edge, int64_t nnz, float *data_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEO_HIP_H */

@@ -1,0 +1,79 @@
+"""Device plumbing shared by the vqvae_amd.geo wrappers: PyTorch-ROCm owns device memory and
+streams, libgeo_hip.so does the arithmetic.  Nothing here computes on the CPU."""
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from . import _lib
+
+
+def device() -> torch.device:
+    """The GPU of this process (one process per GPU: LOCAL_RANK selects it).  Raises without one."""
+    if not torch.cuda.is_available():
+        raise _lib.GeoHipError("vqvae_amd needs an MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for the geodesic-codebook path")
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (288 GB of HBM: keep it resident between calls)."""
+    nbytes = int(nbytes) + 256
+    key = (dev.type, dev.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ws_cache.pop(key, None)
+        buf = None
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspace() -> None:
+    _ws_cache.clear()
+
+
+@dataclass
+class DeviceCSR:
+    """CSR on the GPU: int32 indptr [n+1], int32 indices [nnz], optional f32 data [nnz]."""
+    n: int
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    data: Optional[torch.Tensor]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indices.numel())
+
+    @staticmethod
+    def from_scipy(W: sparse.spmatrix, dev: torch.device, with_data: bool = True) -> "DeviceCSR":
+        W = W.tocsr()
+        if W.nnz >= 2 ** 31 or W.shape[0] >= 2 ** 31 - 1:
+            raise ValueError("graph too large for int32 CSR")
+        indptr = torch.from_numpy(np.ascontiguousarray(W.indptr, dtype=np.int32)).to(dev)
+        indices = torch.from_numpy(np.ascontiguousarray(W.indices, dtype=np.int32)).to(dev)
+        data = None
+        if with_data:
+            data = torch.from_numpy(np.ascontiguousarray(W.data, dtype=np.float32)).to(dev)
+        return DeviceCSR(W.shape[0], indptr, indices, data)
+
+    def to_scipy(self) -> sparse.csr_matrix:
+        data = (self.data.cpu().numpy() if self.data is not None
+                else np.ones(self.nnz, dtype=np.float32))
+        return sparse.csr_matrix((data, self.indices.cpu().numpy(), self.indptr.cpu().numpy()),
+                                 shape=(self.n, self.n))

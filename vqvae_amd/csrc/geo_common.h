@@ -1,0 +1,64 @@
+// geo_common.h -- shared host-side helpers for libgeo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "geo_hip.h"
+
+namespace geo {
+
+void set_error(const char *fmt, ...);
+
+#define GEO_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            geo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GEO_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+#define GEO_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            geo::set_error(__VA_ARGS__);    \
+            return GEO_E_ARG;               \
+        }                                   \
+    } while (0)
+
+#define GEO_LAUNCH_CHECK() GEO_HIP_CHECK(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+    char *base;
+    size_t size, off;
+    Arena(void *p, size_t n) : base(static_cast<char *>(p)), size(n), off(0) {}
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T));
+        if (off + bytes > size) return nullptr;
+        T *r = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+// Exclusive prefix sum of int32 counts into int32 offsets (out[n] = total); returns total on host
+// when total_host != nullptr (synchronises in that case).  tmp: >= scan_tmp_bytes(n).
+size_t scan_tmp_bytes(int64_t n);
+int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, void *tmp, size_t tmp_bytes,
+                       int64_t *total_host, hipStream_t stream);
+
+static inline int grid_for(int64_t work_items, int per_block, int cap = 8192) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return static_cast<int>(g);
+}
+
+}  // namespace geo

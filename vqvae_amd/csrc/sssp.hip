@@ -1,0 +1,368 @@
+// sssp.hip -- fp64 label-correcting shortest paths on a pull CSR (gfx950).
+//
+// Replaces scipy.sparse.csgraph.dijkstra as used by the reference
+// (src/geo/geo_shortest_paths.py:36-49; src/geo/kmeans_optimized.py:43,97,125).
+//
+// Why label-correcting reproduces Dijkstra bit for bit: every value ever stored in dist[] is the
+// left-to-right fp64 sum of the weights along some real path from the source (one rounding per
+// hop), and fl(a + w) is monotone in a.  The iteration d[v] <- min(d[v], min_u fl(d[u] + w(u,v)))
+// therefore decreases towards, and stops exactly at, the same fixed point Dijkstra settles on.
+// Updates are made IN PLACE (chaotic relaxation): a racing reader sees either the old or the new
+// 8-byte value, both valid path sums.  Convergence is declared only by a sweep (one kernel
+// launch) in which no store happened; inside such a launch every read returns the launch-start
+// state (kernel boundaries write back L2 and invalidate L1), so the state is a true fixed point.
+//
+// Layouts
+//   multi-source: dist[batch][node][64] fp64 -- the 64 sources of a batch are the fast axis, so
+//     one wave relaxes one node for 64 sources with 512-byte coalesced row reads while the CSR
+//     row (column ids, weights) is wave-uniform and comes through the scalar cache;
+//   single-source: dist[node] fp64, 16 lanes share one node's adjacency row.
+#include "geo_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int SB = 64;            // sources per batch = lanes per wave
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int SWEEP_GROUP = 4;    // sweeps enqueued between host convergence checks
+
+__device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// ------------------------------------------------------------------------------------ multi-source
+__global__ __launch_bounds__(256) void init_multi_kernel(double *__restrict__ dist, const int32_t *__restrict__ src,
+                                                        int32_t n, int32_t nb) {
+    const int64_t total = (int64_t)nb * n * SB;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i & (SB - 1));
+        const int64_t r = i >> 6;
+        const int32_t v = (int32_t)(r % n);
+        const int32_t b = (int32_t)(r / n);
+        dist[i] = (src[b * SB + s] == v) ? 0.0 : inf64();
+    }
+}
+
+// One sweep over every (batch, node).  flags: ring of 3 slots x nb ints; this sweep reads slot
+// `prev`, sets slot `cur` where something changed and clears slot `next`.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices,
+                                                         const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                         double *dist, int32_t *flags, int prev, int cur, int next,
+                                                         int first) {
+    const int bid = blockIdx.x;
+    const int b = bid % nb;                 // batch <-> XCD affinity when nb is a multiple of 8
+    const int xb = bid / nb;
+    const int nxb = gridDim.x / nb;
+    if (bid == 0)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
+    if (xb >= nxb) return;                  // tail blocks when gridDim.x % nb != 0
+    if (!first && flags[prev * nb + b] == 0) return;   // this batch already reached its fixed point
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *D = dist + (size_t)b * n * SB;
+    bool any = false;
+    for (int32_t v = xb * WAVES_PER_BLOCK + wave; v < n; v += nxb * WAVES_PER_BLOCK) {
+        const int32_t e0 = indptr[v], e1 = indptr[v + 1];
+        const double curv = D[(size_t)v * SB + lane];
+        double best = curv;
+        int32_t e = e0;
+        for (; e + 4 <= e1; e += 4) {
+            const int32_t u0 = indices[e], u1 = indices[e + 1], u2 = indices[e + 2], u3 = indices[e + 3];
+            const double d0 = D[(size_t)u0 * SB + lane], d1 = D[(size_t)u1 * SB + lane];
+            const double d2 = D[(size_t)u2 * SB + lane], d3 = D[(size_t)u3 * SB + lane];
+            const double w0 = WEIGHTED ? (double)weights[e] : 1.0, w1 = WEIGHTED ? (double)weights[e + 1] : 1.0;
+            const double w2 = WEIGHTED ? (double)weights[e + 2] : 1.0, w3 = WEIGHTED ? (double)weights[e + 3] : 1.0;
+            best = fmin(best, fmin(fmin(d0 + w0, d1 + w1), fmin(d2 + w2, d3 + w3)));
+        }
+        for (; e < e1; ++e) {
+            const double w = WEIGHTED ? (double)weights[e] : 1.0;
+            best = fmin(best, D[(size_t)indices[e] * SB + lane] + w);
+        }
+        if (best < curv) {
+            D[(size_t)v * SB + lane] = best;
+            any = true;
+        }
+    }
+    if (__any(any) && lane == 0) flags[cur * nb + b] = 1;
+}
+
+// dist[b][v][s] (fp64) -> out[(b*64+s)][v] (f32), 64x64 tiles through LDS.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void transpose_out_kernel(const TIn *__restrict__ in, TOut *__restrict__ out,
+                                                           int32_t n, int32_t n_sources) {
+    __shared__ TOut tile[64][65];
+    const int b = blockIdx.y;
+    const int32_t v0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int32_t v = v0 + i;
+        if (v < n) tile[i][tx] = (TOut)in[((size_t)b * n + v) * SB + tx];
+    }
+    __syncthreads();
+    for (int s = ty; s < 64; s += 4) {
+        const int32_t row = b * SB + s;
+        const int32_t v = v0 + tx;
+        if (row < n_sources && v < n) out[(size_t)row * n + v] = tile[tx][s];
+    }
+}
+
+// Column minimum of the f32 matrix and the first row attaining it (D.argmin(axis=0)).
+__global__ __launch_bounds__(256) void colmin_kernel(const double *__restrict__ dist, int32_t n, int32_t nb,
+                                                    int32_t n_sources, float *__restrict__ dmin,
+                                                    int32_t *__restrict__ argmin) {
+    const int lane = threadIdx.x & 63;
+    const int32_t v = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (v >= n) return;
+    float best = __int_as_float(0x7f800000);
+    int32_t barg = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int32_t row = b * SB + lane;
+        float val = (row < n_sources) ? (float)dist[((size_t)b * n + v) * SB + lane] : __int_as_float(0x7f800000);
+        int32_t idx = row;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(val, off, 64);
+            const int32_t oi = __shfl_xor(idx, off, 64);
+            if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (val < best) { best = val; barg = idx; }
+    }
+    if (lane == 0) {
+        if (dmin) dmin[v] = best;
+        if (argmin) argmin[v] = barg;
+    }
+}
+
+// Predecessor of every (source, node): the in-neighbour u with fl(d[u] + w) == d[v], smallest d[u]
+// first, then smallest index.  Written as pred[b][v][64] (i32) for the transposing store.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void pred_multi_kernel(const int32_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                        const double *__restrict__ dist, const int32_t *__restrict__ src,
+                                                        int32_t *__restrict__ pred) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double *D = dist + (size_t)b * n * SB;
+    const int32_t mysrc = src[b * SB + lane];
+    for (int32_t v = blockIdx.x * WAVES_PER_BLOCK + wave; v < n; v += gridDim.x * WAVES_PER_BLOCK) {
+        const double dv = D[(size_t)v * SB + lane];
+        int32_t p = -9999;
+        double dp = inf64();
+        if (dv < inf64() && v != mysrc) {
+            for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+                const int32_t u = indices[e];
+                const double du = D[(size_t)u * SB + lane];
+                const double w = WEIGHTED ? (double)weights[e] : 1.0;
+                if (du + w == dv && (du < dp || (du == dp && u < p))) { dp = du; p = u; }
+            }
+        }
+        pred[((size_t)b * n + v) * SB + lane] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------ single source
+__global__ __launch_bounds__(256) void init_single_kernel(double *__restrict__ d, int32_t n, int32_t source,
+                                                         int32_t *flags) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        d[i] = (i == source) ? 0.0 : inf64();
+    if (blockIdx.x == 0 && threadIdx.x < 3) flags[threadIdx.x] = 0;
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void sweep_single_kernel(const int32_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const float *__restrict__ weights, int32_t n, double *d,
+                                                          int32_t *flags, int prev, int cur, int next, int first) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[next] = 0;
+    if (!first && flags[prev] == 0) return;
+    const int sub = threadIdx.x & 15;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ngrp = (gridDim.x * blockDim.x) >> 4;
+    bool any = false;
+    for (int32_t v = grp; v < n; v += ngrp) {
+        const int32_t e0 = indptr[v], e1 = indptr[v + 1];
+        const double curv = d[v];
+        double best = curv;
+        for (int32_t e = e0 + sub; e < e1; e += 16) {
+            const double w = WEIGHTED ? (double)weights[e] : 1.0;
+            best = fmin(best, d[indices[e]] + w);
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 16));
+        if (sub == 0 && best < curv) {
+            d[v] = best;
+            any = true;
+        }
+    }
+    if (any) flags[cur] = 1;
+}
+
+__global__ __launch_bounds__(256) void finish_single_kernel(const double *__restrict__ d, int32_t n,
+                                                           float *__restrict__ d_out, float *__restrict__ dmin,
+                                                           int32_t *__restrict__ argmin, int32_t center_pos) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = (float)d[i];
+        if (d_out) d_out[i] = x;
+        if (dmin && x < dmin[i]) {
+            dmin[i] = x;
+            if (argmin) argmin[i] = center_pos;
+        }
+    }
+}
+
+struct MultiWs {
+    double *dist;
+    int32_t *pred;
+    int32_t *flags;
+    int32_t *src_pad;
+};
+
+size_t multi_bytes(int32_t n, int32_t nb, bool with_pred) {
+    size_t b = geo::align_up((size_t)nb * n * SB * sizeof(double));
+    if (with_pred) b += geo::align_up((size_t)nb * n * SB * sizeof(int32_t));
+    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + geo::align_up((size_t)nb * SB * sizeof(int32_t));
+    return b;
+}
+
+}  // namespace
+
+extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources) {
+    if (n < 0 || n_sources < 0) return 0;
+    const int32_t nb = (n_sources + SB - 1) / SB;
+    size_t multi = multi_bytes(n > 0 ? n : 1, nb > 0 ? nb : 1, true);
+    size_t single = geo::align_up((size_t)(n > 0 ? n : 1) * sizeof(double)) + 256;
+    return (multi > single ? multi : single) + 1024;
+}
+
+extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                              const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
+                              float *dmin_out, int32_t *argmin_out, void *ws, size_t ws_bytes,
+                              int32_t *sweeps_out, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(n > 0 && n_sources > 0, "geo_sssp_multi: n=%d n_sources=%d must be positive", n, n_sources);
+    GEO_REQUIRE(indptr && indices && sources && ws, "geo_sssp_multi: null pointer");
+    const int32_t nb = (n_sources + SB - 1) / SB;
+    if (ws_bytes < multi_bytes(n, nb, P_out != nullptr)) {
+        geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes, multi_bytes(n, nb, P_out != nullptr));
+        return GEO_E_WORKSPACE;
+    }
+    geo::Arena ar(ws, ws_bytes);
+    MultiWs w;
+    w.dist = ar.take<double>((size_t)nb * n * SB);
+    w.pred = P_out ? ar.take<int32_t>((size_t)nb * n * SB) : nullptr;
+    w.flags = ar.take<int32_t>(3 * (size_t)nb);
+    w.src_pad = ar.take<int32_t>((size_t)nb * SB);
+
+    GEO_HIP_CHECK(hipMemsetAsync(w.src_pad, 0xff, (size_t)nb * SB * sizeof(int32_t), stream));   // -1 = no source
+    GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, sources, (size_t)n_sources * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)nb * sizeof(int32_t), stream));
+    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * SB, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb);
+    GEO_LAUNCH_CHECK();
+
+    // grid: a multiple of nb so that block -> (batch, node slice) is exact
+    const int per_batch = geo::grid_for(n, WAVES_PER_BLOCK, nb >= 8192 ? 1 : 8192 / nb);
+    const unsigned grid = (unsigned)per_batch * (unsigned)nb;
+    std::vector<int32_t> hflags(nb);
+    int32_t sweeps = 0;
+    bool done = false;
+    const int64_t limit = (int64_t)n + 2;
+    while (!done) {
+        int last_cur = 0;
+        for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
+            const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
+            if (weights)
+                sweep_multi_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.flags,
+                                                                   prev, cur, next, sweeps == 0);
+            else
+                sweep_multi_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.flags,
+                                                                    prev, cur, next, sweeps == 0);
+            GEO_LAUNCH_CHECK();
+            last_cur = cur;
+        }
+        GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        done = true;
+        for (int32_t b = 0; b < nb; ++b) done = done && (hflags[b] == 0);
+        if (!done && sweeps > limit) {
+            geo::set_error("geo_sssp_multi: no fixed point after %d sweeps", sweeps);
+            return GEO_E_NOCONV;
+        }
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
+    if (D_out) {
+        transpose_out_kernel<double, float><<<tgrid, 256, 0, stream>>>(w.dist, D_out, n, n_sources);
+        GEO_LAUNCH_CHECK();
+    }
+    if (P_out) {
+        const dim3 pgrid((unsigned)geo::grid_for(n, WAVES_PER_BLOCK, 4096), (unsigned)nb);
+        if (weights)
+            pred_multi_kernel<true><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.src_pad, w.pred);
+        else
+            pred_multi_kernel<false><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.src_pad, w.pred);
+        GEO_LAUNCH_CHECK();
+        transpose_out_kernel<int32_t, int32_t><<<tgrid, 256, 0, stream>>>(w.pred, P_out, n, n_sources);
+        GEO_LAUNCH_CHECK();
+    }
+    if (dmin_out || argmin_out) {
+        colmin_kernel<<<(unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), 256, 0, stream>>>(
+            w.dist, n, nb, n_sources, dmin_out, argmin_out);
+        GEO_LAUNCH_CHECK();
+    }
+    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    return GEO_OK;
+}
+
+extern "C" int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                                      int32_t source, float *d_out, float *dmin_inout, int32_t *argmin_inout,
+                                      int32_t center_pos, void *ws, size_t ws_bytes, int32_t *sweeps_out,
+                                      void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(n > 0 && source >= 0 && source < n, "geo_sssp_single_update: bad n=%d source=%d", n, source);
+    GEO_REQUIRE(indptr && indices && ws, "geo_sssp_single_update: null pointer");
+    geo::Arena ar(ws, ws_bytes);
+    double *d = ar.take<double>((size_t)n);
+    int32_t *flags = ar.take<int32_t>(4);
+    if (!d || !flags) {
+        geo::set_error("geo_sssp_single_update: workspace too small");
+        return GEO_E_WORKSPACE;
+    }
+    const int grid1 = geo::grid_for(n, 256, 2048);
+    init_single_kernel<<<grid1, 256, 0, stream>>>(d, n, source, flags);
+    GEO_LAUNCH_CHECK();
+    const int grid = geo::grid_for(n, 16, 2048);      // 16 nodes per 256-thread block
+    int32_t sweeps = 0, hflag = 1;
+    const int64_t limit = (int64_t)n + 2;
+    while (hflag) {
+        int last_cur = 0;
+        for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
+            const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
+            if (weights)
+                sweep_single_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
+                                                                    next, sweeps == 0);
+            else
+                sweep_single_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
+                                                                     next, sweeps == 0);
+            GEO_LAUNCH_CHECK();
+            last_cur = cur;
+        }
+        GEO_HIP_CHECK(hipMemcpyAsync(&hflag, flags + last_cur, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (hflag && sweeps > limit) {
+            geo::set_error("geo_sssp_single_update: no fixed point after %d sweeps", sweeps);
+            return GEO_E_NOCONV;
+        }
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    finish_single_kernel<<<grid1, 256, 0, stream>>>(d, n, d_out, dmin_inout, argmin_inout, center_pos);
+    GEO_LAUNCH_CHECK();
+    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    return GEO_OK;
+}
