@@ -1,0 +1,170 @@
+"""GPU parity of csrc/knn.hip + csrc/graph.hip through vqvae_amd.geo.knn_graph_optimized against the
+golden vectors (reference outputs), the oracle, and the reference's structural tests
+(reference tests/test_knn_graph.py, tests/test_integration_knn_geo.py)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import clustered_latents, csr_from_golden, latents
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"g16": (2048, 16, 0), "g32": (512, 32, 1), "g64": (300, 64, 2), "g8": (400, 8, 3)}
+
+
+def _ulp_diff(a, b):
+    return np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.abs(b).astype(np.float32)))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_graph_structure_and_weights(golden, name):
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph_auto
+    g = golden("knn")
+    N, d, seed = CASES[name]
+    z = latents(N, d, seed)
+    for k in (1, 5, 20):
+        for mode in ("connectivity", "distance"):
+            for sym in ("union", "mutual"):
+                tag = f"{name}/k{k}/{mode}/{sym}"
+                W, info = build_knn_graph_auto(z, k=k, mode=mode, sym=sym)
+                assert isinstance(W, sp.csr_matrix) and W.dtype == np.float32 and W.shape == (N, N)
+                assert W.has_sorted_indices
+                np.testing.assert_array_equal(W.indptr, g[f"{tag}/indptr"], err_msg=tag)
+                np.testing.assert_array_equal(W.indices, g[f"{tag}/indices"], err_msg=tag)
+                if mode == "distance":
+                    assert _ulp_diff(W.data, g[f"{tag}/data"]) <= 1.0, tag       # <= 1 ulp f32 (SURVEY 8a gate)
+                else:
+                    assert (W.data == 1.0).all()
+        # neighbour lists: same sets, same order (distinct distances), distances within 1 ulp
+        assert info["indices"].dtype == np.int64 and info["distances"].dtype == np.float32
+        np.testing.assert_array_equal(info["indices"], g[f"{name}/k{k}/nbr_indices"])
+        assert _ulp_diff(info["distances"], g[f"{name}/k{k}/nbr_distances"]) <= 1.0
+
+
+def test_duplicates_match_modulo_ties(golden):
+    """Exactly tied fp64 distances (duplicate latents) are ordered by heap accident in sklearn; ours are
+    ordered by index.  Everything not involving a tie must still agree with the reference."""
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph_auto
+    from oracle import knn as okn
+    g = golden("knn")
+    z = clustered_latents(256, 16, 4)
+    dup_nodes = {3, 5, 15, 16, 17, 128, 255}
+    for k in (1, 5, 20):
+        for mode in ("connectivity", "distance"):
+            for sym in ("union", "mutual"):
+                W, info = build_knn_graph_auto(z, k=k, mode=mode, sym=sym)
+                Wo, info_o = okn.build_knn_graph_auto(z, k=k, mode=mode, sym=sym)
+                # bit-identical to the oracle (same tie rule) ...
+                np.testing.assert_array_equal(W.indptr, Wo.indptr)
+                np.testing.assert_array_equal(W.indices, Wo.indices)
+                np.testing.assert_array_equal(info["indices"], info_o["indices"])
+                # ... and equal to the reference away from the duplicated points
+                Wr = csr_from_golden(g, f"dup16/k{k}/{mode}/{sym}", 256, with_data=False)
+                diff = (abs(sp.csr_matrix((np.ones(W.nnz), W.indices, W.indptr), shape=W.shape) - Wr)).tocoo()
+                touched = set(diff.row[diff.data != 0]) | set(diff.col[diff.data != 0])
+                assert all((r in dup_nodes) or (c in dup_nodes) for r, c in zip(diff.row, diff.col)), touched
+        ref_d = g[f"dup16/k{k}/nbr_distances"]
+        assert _ulp_diff(info["distances"] + 1, ref_d + 1) <= 64       # same distance multisets row by row
+
+
+def test_reference_edge_cases():
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph
+    W, nb = build_knn_graph(np.empty((0, 8), np.float32), k=10)
+    assert isinstance(W, sp.csr_matrix) and W.shape == (0, 0)
+    assert nb["distances"].shape == (0, 0) and nb["indices"].shape == (0, 0)
+    W, nb = build_knn_graph(latents(1, 8, 0), k=10)
+    assert W.shape == (1, 1) and nb["distances"].shape == (1, 0) and nb["indices"].shape == (1, 0)
+    W, nb = build_knn_graph(latents(25, 4, 0), k=0)
+    assert W.nnz == 0 and nb["indices"].shape == (25, 0)
+    W, nb = build_knn_graph(latents(5, 4, 0), k=10)
+    assert nb["distances"].shape == (5, 4) and nb["indices"].shape == (5, 4) and W.shape == (5, 5)
+    with pytest.raises(ValueError):
+        build_knn_graph(latents(20, 4, 0), k=3, sym="bogus")
+    with pytest.raises(AssertionError):
+        build_knn_graph(np.zeros(7, np.float32), k=3)
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph_auto
+    with pytest.raises(RuntimeError):
+        build_knn_graph_auto(latents(20, 4, 0), k=3, force_method="faiss")
+
+
+def test_structural_properties():
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph
+    z = latents(200, 8, 0)
+    W, nb = build_knn_graph(z, k=10)
+    assert (W - W.T).nnz == 0 and float(W.diagonal().sum()) == 0.0
+    rows = np.arange(200)[:, None]
+    assert not np.any(nb["indices"] == rows)
+    Wd, _ = build_knn_graph(latents(120, 6, 0), k=8, mode="distance")
+    assert np.all(Wd.data >= 0.0)
+
+
+def test_ragged_sizes_vs_oracle():
+    """N not a multiple of the 64-lane step, odd d (zero padded), k+1 up to the 64-lane list."""
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph
+    from oracle import knn as okn
+    for N, d, k in ((65, 3, 7), (130, 17, 63), (1000, 33, 20), (777, 100, 5), (64, 16, 63)):
+        z = latents(N, d, N + d)
+        W, info = build_knn_graph(z, k=k, mode="distance", sym="union")
+        Wo, info_o = okn.build_knn_graph(z, k=k, mode="distance", sym="union")
+        np.testing.assert_array_equal(info["indices"], info_o["indices"], err_msg=str((N, d, k)))
+        np.testing.assert_array_equal(W.indices, Wo.indices)
+        np.testing.assert_array_equal(W.indptr, Wo.indptr)
+        np.testing.assert_array_equal(W.data, Wo.data)
+
+
+def test_lcc_and_connectivity(golden):
+    from vqvae_amd.geo.knn_graph_optimized import (analyze_graph_connectivity, build_knn_graph,
+                                                   largest_connected_component)
+    from oracle import knn as okn
+    gs = golden("sssp")
+    W, _ = build_knn_graph(latents(240, 12, 1), k=1, mode="distance", sym="mutual")
+    mask = largest_connected_component(W)
+    assert mask.dtype == bool
+    np.testing.assert_array_equal(mask, gs["disc/lcc"])
+    stats = analyze_graph_connectivity(W)
+    ref = okn.analyze_graph_connectivity(W)
+    for key in ("n_nodes", "n_edges", "n_components", "largest_component_size"):
+        assert stats[key] == ref[key], key
+    Wc, _ = build_knn_graph(latents(300, 8, 5), k=10, sym="union")
+    assert largest_connected_component(Wc).all()
+    # scipy label order: components numbered by their lowest node
+    from vqvae_amd.geo.knn_graph_optimized import _undirected_structure, connected_components_device
+    from vqvae_amd._device import device
+    n, labels = connected_components_device(_undirected_structure(W, device()))
+    no, lo = okn.connected_components(W)
+    assert n == no
+    np.testing.assert_array_equal(labels.cpu().numpy(), lo)
+
+
+def test_upper_edges_and_reweight_vs_oracle():
+    import torch
+    from oracle import pipeline as op
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.knn_graph_optimized import (build_knn_graph, compact_device, reweight_device,
+                                                   upper_edges_device)
+    W, _ = build_knn_graph(latents(500, 16, 9), k=6, mode="connectivity", sym="union")
+    dev = device()
+    G = DeviceCSR.from_scipy(W, dev)
+    src, dst, entry_edge = upper_edges_device(G)
+    edges = op.upper_edges(W)
+    np.testing.assert_array_equal(src.cpu().numpy(), edges[:, 0])
+    np.testing.assert_array_equal(dst.cpu().numpy(), edges[:, 1])
+    lengths = np.random.RandomState(0).rand(len(edges)).astype(np.float32)
+    lengths[::17] = 0.0                                     # zero-length edges vanish from U + U^T
+    Wg = reweight_device(G, entry_edge, torch.from_numpy(lengths).to(dev))
+    Wz, _ = compact_device(Wg, None, drop_zero=True)
+    ref = op.reweighted_graph(500, edges, lengths)
+    ref.sort_indices()
+    got = Wz.to_scipy()
+    np.testing.assert_array_equal(got.indptr, ref.indptr)
+    np.testing.assert_array_equal(got.indices, ref.indices)
+    np.testing.assert_array_equal(got.data, ref.data)
+    # node compaction = W[mask][:, mask]
+    mask = np.random.RandomState(1).rand(500) > 0.3
+    Wm, new_index = compact_device(Wz, torch.from_numpy(mask).to(dev), drop_zero=False)
+    refm = ref[mask][:, mask]
+    refm.sort_indices()
+    gotm = Wm.to_scipy()
+    np.testing.assert_array_equal(gotm.indptr, refm.indptr)
+    np.testing.assert_array_equal(gotm.indices, refm.indices)
+    np.testing.assert_array_equal(gotm.data, refm.data)

@@ -1,0 +1,117 @@
+"""GPU parity of csrc/jvp.hip through vqvae_amd.geo.riemannian_metric against the reference's edge
+lengths (golden) and the fp64 closed-form oracle; plus the reference's own property tests
+(reference tests/test_riemannian_metric.py) on the generic-decoder path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEC_CASES = {"fm_batch": (16, 1, 28, "batch", 10), "fm_none": (16, 1, 28, "none", 11),
+             "cf_batch": (32, 3, 32, "batch", 13)}
+E = 2048
+# SURVEY 8(a) gate: >= 99.9 % of edges within 1e-5 relative of the reference f32 output; every edge within
+# 1e-5 of the fp64 closed form unless a ReLU pre-activation sits on its rounding boundary (rare outliers).
+TOL = 1e-5
+
+
+def _decoder(name, training):
+    from oracle import metric as om
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    d, cout, size, norm, seed = DEC_CASES[name]
+    sd = om.make_decoder_state(seed, d, cout, norm_type=norm)
+    dec = SpatialDecoder(cout, (256, 128, 64), d, size, norm)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec.train(training)
+    r = np.random.RandomState(100 + seed)
+    zs = r.randn(E, d).astype(np.float32)
+    ze = (zs + 0.3 * r.randn(E, d)).astype(np.float32)
+    return dec, sd, zs, ze, (d, cout, size, norm)
+
+
+@pytest.mark.parametrize("name", list(DEC_CASES))
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("bs", [512, 100])
+def test_edge_lengths_vs_reference_and_fp64(golden, name, training, bs):
+    from oracle import metric as om
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    dec, sd, zs, ze, (d, cout, size, norm) = _decoder(name, training)
+    dec = dec.cuda()
+    L = edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs)
+    assert L.is_cuda and L.dtype == torch.float32 and L.shape == (E,)
+    L = L.cpu().numpy()
+    ref = golden("metric")[f"{name}/train{int(training)}/bs{bs}"]
+    rel = np.abs(L - ref) / np.abs(ref)
+    assert np.mean(rel <= TOL) >= 0.999, (rel.max(), np.quantile(rel, 0.999))
+    L64 = om.edge_lengths(sd, norm, size, zs, ze, batch_size=bs, training=training, dtype=torch.float64).numpy()
+    rel64 = np.abs(L - L64) / np.abs(L64)
+    assert np.mean(rel64 <= TOL) >= 0.999, (rel64.max(), np.quantile(rel64, 0.999))
+    assert np.quantile(rel64, 0.99) < 2e-6
+
+
+def test_decoder_on_cpu_result_returns_to_cpu():
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    dec, sd, zs, ze, _ = _decoder("fm_batch", False)
+    L = edge_lengths_riemannian(dec, torch.from_numpy(zs[:100]), torch.from_numpy(ze[:100]), batch_size=32)
+    assert not L.is_cuda and L.shape == (100,)
+    dec2 = dec.cuda()
+    L2 = edge_lengths_riemannian(dec2, torch.from_numpy(zs[:100]).cuda(), torch.from_numpy(ze[:100]).cuda(), batch_size=32)
+    np.testing.assert_array_equal(L.numpy(), L2.cpu().numpy())
+
+
+def test_eval_mode_is_batch_size_invariant_and_train_mode_is_not():
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    dec, sd, zs, ze, _ = _decoder("fm_batch", False)
+    dec = dec.cuda()
+    a = edge_lengths_riemannian(dec, torch.from_numpy(zs[:300]), torch.from_numpy(ze[:300]), batch_size=512)
+    b = edge_lengths_riemannian(dec, torch.from_numpy(zs[:300]), torch.from_numpy(ze[:300]), batch_size=37)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    dec.train(True)
+    c = edge_lengths_riemannian(dec, torch.from_numpy(zs[:300]), torch.from_numpy(ze[:300]), batch_size=512)
+    e = edge_lengths_riemannian(dec, torch.from_numpy(zs[:300]), torch.from_numpy(ze[:300]), batch_size=37)
+    assert not torch.allclose(c, e, rtol=1e-3)            # batch statistics couple the samples (SURVEY finding 4)
+
+
+def test_graph_edge_entry_point_matches_pairs():
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_device, edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport
+    dec, sd, zs, ze, _ = _decoder("fm_batch", True)
+    dev = device()
+    z = torch.from_numpy(zs[:400]).to(dev)
+    r = np.random.RandomState(3)
+    src = torch.from_numpy(r.randint(0, 400, 1000).astype(np.int32)).to(dev)
+    dst = torch.from_numpy(r.randint(0, 400, 1000).astype(np.int32)).to(dev)
+    ex = DecoderExport(dec.to(dev), dev)
+    a = edge_lengths_graph_device(ex, z, src, dst, 512)
+    b = edge_lengths_device(ex, z[src.long()].contiguous(), z[dst.long()].contiguous(), 512)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+class DummyDec(torch.nn.Module):
+    """Linear test decoder of the reference's tests/test_riemannian_metric.py:6-14."""
+
+    def __init__(self, d=16, hw=28 * 28):
+        super().__init__()
+        self.lin = torch.nn.Linear(d, hw)
+
+    def forward(self, z):
+        return self.lin(z).view(z.size(0), 1, 28, 28)
+
+
+def _pairs(M=64, D=16, eps=0.1, seed=42, device="cpu"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    zi = torch.randn(M, D, generator=g, device=device)
+    return zi, zi + eps * torch.randn(M, D, generator=g, device=device)
+
+
+def test_generic_decoder_properties_on_gpu():
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    dec = DummyDec().eval().cuda()
+    zi, zj = _pairs(device="cuda")
+    L = edge_lengths_riemannian(dec, zi, zj, batch_size=32)
+    assert L.is_cuda and L.dtype == torch.float32 and L.shape == (64,) and torch.all(L >= 0)
+    assert torch.allclose(L, edge_lengths_riemannian(dec, zj, zi, batch_size=64), rtol=1e-4, atol=1e-6)
+    zi, zj = _pairs(M=127, device="cuda")
+    assert torch.allclose(edge_lengths_riemannian(dec, zi, zj, batch_size=16),
+                          edge_lengths_riemannian(dec, zi, zj, batch_size=1024), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,588 @@
+// jvp.hip -- decoder pull-back edge lengths by forward-mode tangent propagation (gfx950).
+//
+// Replaces torch.autograd.functional.jvp through SpatialDecoder in the reference
+// (src/geo/riemannian_metric.py:12-35,37-66 over src/models/spatial_vae.py:47-81):
+//     len[e] = 0.5 * ( |J(z_i) dz| + |J(z_j) dz| ),  dz = z_j - z_i,  J = d sigmoid(decoder(z)) / dz
+// with the decoder applied to a 1x1 latent "image":
+//     conv1x1(d->c0) -> ConvT(c0->c1,k4,s2,p1): 1x1 -> 2x2 -> norm -> ReLU
+//                    -> ConvT(c1->c2,k4,s2,p1): 2x2 -> 4x4 -> norm -> ReLU
+//                    -> ConvT(c2->co,k4,s2,p=3|1): 4x4 -> 4x4 | 8x8 -> sigmoid.
+// The tangent is pushed through next to the primal (one pass instead of autograd's forward +
+// double backward).  Edges are processed in chunks of `batch_size` consecutive edges; each
+// (chunk, endpoint side) is one BatchNorm batch, exactly the batches riemannian_metric.py:50-58
+// feeds to the decoder, so train-mode batch statistics see the same samples.
+//
+// Kernels (activations are laid out [slot][pixel][channel], slot = padded sample position):
+//   front  (VALU)  pre1 = z . M01 + b01, M01 = conv_in o ConvT1 composed once in fp64 (no
+//                  nonlinearity sits between them); per-tile partial BN sums in fp64.
+//   mid    (MFMA)  v_mfma_f32_32x32x2_f32 GEMM for ConvT2 as a block-sparse product over
+//                  (input pixel -> output pixel) blocks; prologue = norm1 + ReLU on primal and
+//                  tangent while staging A into LDS; epilogue = bias, store, partial BN sums.
+//   back   (VALU)  norm2 + ReLU, ConvT3, sigmoid', squared norm per sample.
+#include "geo_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int TS = 32;          // samples per tile (= one 32-row MFMA slice for primal, one for tangent)
+constexpr int NC = 128;         // output columns per mid-kernel workgroup (4 waves x 32)
+constexpr int MAX_BLOCKS = 4;   // input pixels feeding one output pixel (2x2 input)
+constexpr int BACK_TS = 8;      // samples per back-kernel workgroup
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Shape {
+    int d, c0, c1, c2, co, s_out, pad3, p_out;   // p_out = co * s_out * s_out
+    int n1, n2;                                   // 4*c1, 16*c2
+    int opix_per_chunk, n_chunks;
+};
+
+struct ChunkTable {
+    int nblk[16];
+    int ipix[16][MAX_BLOCKS];
+    int opix[16][16];
+};
+
+// prologue constants per (stat row, channel): y = (x - mu) * sc + beta ; t' = sc * (t - mt - (x - mu) * c5)
+struct NormConst { float mu, sc, beta, mt, c5; };
+
+// ---------------------------------------------------------------------------------- weight prep
+// M01[k][n], n = px*c1 + co, px = oy*2+ox: composition of conv_in and ConvT1 (taps ky=oy+1,kx=ox+1)
+__global__ __launch_bounds__(256) void compose_front_kernel(const float *__restrict__ w_in, const float *__restrict__ b_in,
+                                                           const float *__restrict__ w1, const float *__restrict__ b1,
+                                                           int d, int c0, int c1, float *__restrict__ M01,
+                                                           float *__restrict__ b01) {
+    const int n1 = 4 * c1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (d + 1) * n1; i += gridDim.x * blockDim.x) {
+        const int k = i / n1, n = i % n1;
+        const int px = n / c1, co = n % c1;
+        const int ky = (px >> 1) + 1, kx = (px & 1) + 1;
+        double s = 0.0;
+        for (int ci = 0; ci < c0; ++ci) {
+            const double m1 = (double)w1[(((size_t)ci * c1 + co) * 4 + ky) * 4 + kx];
+            const double a = k < d ? (double)w_in[(size_t)ci * d + k] : (double)b_in[ci];
+            s = fma(a, m1, s);
+        }
+        if (k < d) M01[(size_t)k * n1 + n] = (float)s;
+        else b01[n] = (float)(s + (double)b1[co]);
+    }
+}
+
+// B2p[chunk][blk][k = ci][col], col = local output pixel * c2 + co; zero where the tap is out of range
+__global__ __launch_bounds__(256) void pack_mid_kernel(const float *__restrict__ w2, int c1, int c2, ChunkTable tab,
+                                                      int n_chunks, int opix_per_chunk, float *__restrict__ B2p) {
+    const size_t per_blk = (size_t)c1 * NC;
+    const size_t total = (size_t)n_chunks * MAX_BLOCKS * per_blk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % NC);
+        const int ci = (int)((i / NC) % c1);
+        const int blk = (int)((i / per_blk) % MAX_BLOCKS);
+        const int ch = (int)(i / (per_blk * MAX_BLOCKS));
+        float v = 0.0f;
+        const int lo = col / c2, co = col % c2;
+        if (blk < tab.nblk[ch] && lo < opix_per_chunk) {
+            const int op = tab.opix[ch][lo], ip = tab.ipix[ch][blk];
+            const int ky = (op >> 2) + 1 - 2 * (ip >> 1), kx = (op & 3) + 1 - 2 * (ip & 1);
+            if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = w2[(((size_t)ci * c2 + co) * 4 + ky) * 4 + kx];
+        }
+        B2p[i] = v;
+    }
+}
+
+// W3p[ky][kx][co][ci]
+__global__ __launch_bounds__(256) void pack_back_kernel(const float *__restrict__ w3, int c2, int co_n,
+                                                       float *__restrict__ W3p) {
+    const int total = 16 * co_n * c2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % c2, co = (i / c2) % co_n, t = i / (c2 * co_n);
+        W3p[i] = w3[(((size_t)ci * co_n + co) * 4 + (t >> 2)) * 4 + (t & 3)];
+    }
+}
+
+// ---------------------------------------------------------------------------------- front
+// One workgroup = one tile of TS sample slots.  Thread owns output columns n = tid + 256*j for
+// all TS samples, so per-column sums need no cross-thread reduction.
+template <int DMAX>
+__global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z, const int32_t *__restrict__ src,
+                                                   const int32_t *__restrict__ dst, const float *__restrict__ z_start,
+                                                   const float *__restrict__ z_end, int64_t e_base, int64_t n_edges,
+                                                   int batch, int tiles_per_group, int d, int n1,
+                                                   const float *__restrict__ M01, const float *__restrict__ b01,
+                                                   float *__restrict__ pre, float *__restrict__ tpre,
+                                                   double *__restrict__ partial, int want_stats) {
+    __shared__ float zp[TS][DMAX + 1];
+    __shared__ float dz[TS][DMAX + 1];
+    __shared__ int valid_s[TS];
+    const int tile = blockIdx.x;
+    const int group = tile / tiles_per_group, tg = tile % tiles_per_group;
+    const int chunk = group >> 1, side = group & 1;
+    for (int i = threadIdx.x; i < TS * d; i += 256) {
+        const int s = i / d, k = i % d;
+        const int within = tg * TS + s;
+        const int64_t e = e_base + (int64_t)chunk * batch + within;
+        float a = 0.f, b = 0.f;
+        const bool ok = within < batch && e < n_edges;
+        if (ok) {
+            if (src) {
+                a = z[(int64_t)src[e] * d + k];
+                b = z[(int64_t)dst[e] * d + k];
+            } else {
+                a = z_start[e * d + k];
+                b = z_end[e * d + k];
+            }
+        }
+        zp[s][k] = side == 0 ? a : b;
+        dz[s][k] = b - a;
+        if (k == 0) valid_s[s] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const size_t slot0 = (size_t)tile * TS;
+    for (int n = threadIdx.x; n < n1; n += 256) {
+        float m[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) m[k] = k < d ? M01[(size_t)k * n1 + n] : 0.f;
+        const float bias = b01[n];
+        double sx = 0, sxx = 0, st = 0, sxt = 0;
+        for (int s = 0; s < TS; ++s) {
+            float x = bias, t = 0.f;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                x = fmaf(zp[s][k], m[k], x);
+                t = fmaf(dz[s][k], m[k], t);
+            }
+            pre[(slot0 + s) * n1 + n] = x;
+            tpre[(slot0 + s) * n1 + n] = t;
+            if (valid_s[s]) {
+                sx += x; sxx += (double)x * x; st += t; sxt += (double)x * t;
+            }
+        }
+        if (want_stats) {
+            double *p = partial + ((size_t)tile * n1 + n) * 4;
+            p[0] = sx; p[1] = sxx; p[2] = st; p[3] = sxt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- norm constants
+// mode 1 (batch statistics): reduce the per-tile partial sums of a group over tiles and pixels.
+// partial: [tile][npx*C][4] fp64.  consts: [group][C].
+__global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__restrict__ partial, int tiles_per_group,
+                                                            int npx, int C, int64_t e_base, int64_t n_edges,
+                                                            int batch, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps,
+                                                            NormConst *__restrict__ consts, int n_groups) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups * C; i += gridDim.x * blockDim.x) {
+        const int g = i / C, c = i % C;
+        const int chunk = g >> 1;
+        int64_t cnt = n_edges - (e_base + (int64_t)chunk * batch);
+        if (cnt > batch) cnt = batch;
+        if (cnt < 0) cnt = 0;
+        double sx = 0, sxx = 0, st = 0, sxt = 0;
+        for (int t = 0; t < tiles_per_group; ++t)
+            for (int px = 0; px < npx; ++px) {
+                const double *p = partial + (((size_t)(g * tiles_per_group + t)) * npx * C + (size_t)px * C + c) * 4;
+                sx += p[0]; sxx += p[1]; st += p[2]; sxt += p[3];
+            }
+        const double n = (double)cnt * npx;
+        NormConst k;
+        if (n > 0) {
+            const double mu = sx / n;
+            double var = sxx / n - mu * mu;
+            if (var < 0) var = 0;
+            const double inv = 1.0 / sqrt(var + (double)eps);
+            const double mt = st / n;
+            const double mxt = (sxt - mu * st) * inv / n;      // mean(xhat * t)
+            k.mu = (float)mu; k.sc = (float)(inv * gamma[c]); k.beta = beta[c];
+            k.mt = (float)mt; k.c5 = (float)(inv * mxt);
+        } else {
+            k.mu = 0; k.sc = 0; k.beta = 0; k.mt = 0; k.c5 = 0;
+        }
+        consts[i] = k;
+    }
+}
+
+// mode 0 (none) / running statistics: one row of constants shared by every group.
+__global__ void finalize_fixed_kernel(int C, int norm, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                      const float *__restrict__ rm, const float *__restrict__ rv, float eps,
+                                      NormConst *__restrict__ consts) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        NormConst k;
+        if (norm == 1) {
+            const double inv = 1.0 / sqrt((double)rv[c] + (double)eps);
+            k.mu = rm[c]; k.sc = (float)(inv * gamma[c]); k.beta = beta[c];
+        } else {
+            k.mu = 0.f; k.sc = 1.f; k.beta = 0.f;
+        }
+        k.mt = 0.f; k.c5 = 0.f;
+        consts[c] = k;
+    }
+}
+
+__device__ __forceinline__ void norm_relu(const NormConst &k, float x, float t, float *a, float *ta) {
+    const float xc = x - k.mu;
+    const float y = fmaf(xc, k.sc, k.beta);
+    const float tt = k.sc * (t - k.mt - xc * k.c5);
+    *a = y > 0.f ? y : 0.f;
+    *ta = y > 0.f ? tt : 0.f;
+}
+
+// ---------------------------------------------------------------------------------- mid (MFMA)
+// grid = (tiles, chunks).  LDS: A_p / A_t [TS][c1+1] f32 for the current input pixel.
+// Wave w computes columns [32w, 32w+32) of the chunk for the 32 primal and the 32 tangent rows.
+template <int C1>
+__global__ __launch_bounds__(256) void mid_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                                 const NormConst *__restrict__ consts1, int consts_per_group,
+                                                 int tiles_per_group, ChunkTable tab, int opix_per_chunk, int c2,
+                                                 const float *__restrict__ B2p, const float *__restrict__ b2,
+                                                 float *__restrict__ pre2, float *__restrict__ tpre2,
+                                                 double *__restrict__ partial2, int want_stats,
+                                                 const int32_t *__restrict__ slot_valid) {
+    constexpr int LDA = C1 + 1;
+    __shared__ float Ap[TS * LDA];
+    __shared__ float At[TS * LDA];
+    __shared__ NormConst kc[C1];
+    const int tile = blockIdx.x, chunk = blockIdx.y;
+    const int group = tile / tiles_per_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n1 = 4 * C1, n2 = 16 * c2;
+    const size_t slot0 = (size_t)tile * TS;
+    for (int c = threadIdx.x; c < C1; c += 256) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
+
+    f32x16 accp, acct;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
+
+    const int nblk = tab.nblk[chunk];
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int ip = tab.ipix[chunk][blk];
+        __syncthreads();                       // previous block's MFMA reads are done (and kc is visible)
+        // stage A: thread -> (sample = tid/8, 16 consecutive channels)
+        {
+            const int s = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * (C1 / 8);
+            const float *xp = pre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+            const float *xt = tpre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+#pragma unroll
+            for (int k = 0; k < C1 / 8; ++k) {
+                float a, ta;
+                norm_relu(kc[k0 + k], xp[k], xt[k], &a, &ta);
+                Ap[s * LDA + k0 + k] = a;
+                At[s * LDA + k0 + k] = ta;
+            }
+        }
+        // B fragment of this block: lane holds B[k = 2*st + (lane>>5)][col = 32*wave + (lane&31)]
+        float breg[C1 / 2];
+        const float *bsrc = B2p + (((size_t)chunk * MAX_BLOCKS + blk) * C1 + (lane >> 5)) * NC + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int st = 0; st < C1 / 2; ++st) breg[st] = bsrc[(size_t)st * 2 * NC];
+        __syncthreads();
+        const float *ap = Ap + (lane & 31) * LDA + (lane >> 5);
+        const float *at = At + (lane & 31) * LDA + (lane >> 5);
+#pragma unroll
+        for (int st = 0; st < C1 / 2; ++st) {
+            accp = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], breg[st], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x2f32(at[2 * st], breg[st], acct, 0, 0, 0);
+        }
+    }
+
+    // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+    const int col = wave * 32 + (lane & 31);
+    const int lo = col / c2, co = col % c2;
+    const bool col_ok = lo < opix_per_chunk;
+    const int op = col_ok ? tab.opix[chunk][lo] : 0;
+    const float bias = col_ok ? b2[co] : 0.f;
+    double sx = 0, sxx = 0, st_ = 0, sxt = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float x = accp[r] + bias, t = acct[r];
+        if (col_ok) {
+            pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
+            tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
+            if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
+        }
+    }
+    if (want_stats) {
+        sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+        st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+        if (lane < 32 && col_ok) {
+            double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
+            p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
+                                                        int64_t n_slots, int32_t *__restrict__ slot_valid) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per_group = (int64_t)tiles_per_group * TS;
+        const int64_t g = i / per_group, within = i % per_group;
+        const int64_t e = e_base + (g >> 1) * batch + within;
+        slot_valid[i] = (within < batch && e < n_edges) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------- back
+// One workgroup = BACK_TS sample slots.  a2 / ta2 [BACK_TS][16 px][c2] in LDS (dynamic).
+__global__ __launch_bounds__(256) void back_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
+                                                  const NormConst *__restrict__ consts2, int consts_per_group,
+                                                  int slots_per_group, int c2, int co_n, int s_out, int pad3,
+                                                  const float *__restrict__ W3p, const float *__restrict__ b3,
+                                                  float *__restrict__ norms) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n2 = 16 * c2;
+    float *a2 = smem;                                   // [BACK_TS][n2]
+    float *ta2 = smem + (size_t)BACK_TS * n2;           // [BACK_TS][n2]
+    float *jt2 = ta2 + (size_t)BACK_TS * n2;            // [BACK_TS][p_out]
+    const int p_out = co_n * s_out * s_out;
+    const size_t slot0 = (size_t)blockIdx.x * BACK_TS;
+    const int group = (int)(slot0 / slots_per_group);
+    const NormConst *kc = consts2 + (size_t)(consts_per_group ? group : 0) * c2;
+    for (int i = threadIdx.x; i < BACK_TS * n2; i += 256) {
+        const int c = i % c2;
+        float a, ta;
+        norm_relu(kc[c], pre2[slot0 * n2 + i], tpre2[slot0 * n2 + i], &a, &ta);
+        a2[i] = a;
+        ta2[i] = ta;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BACK_TS * p_out; item += 256) {
+        const int s = item / p_out, o = item % p_out;
+        const int co = o / (s_out * s_out), oy = (o / s_out) % s_out, ox = o % s_out;
+        float x = b3[co], t = 0.f;
+        for (int iy = 0; iy < 4; ++iy) {
+            const int ky = oy + pad3 - 2 * iy;
+            if (ky < 0 || ky > 3) continue;
+            for (int ix = 0; ix < 4; ++ix) {
+                const int kx = ox + pad3 - 2 * ix;
+                if (kx < 0 || kx > 3) continue;
+                const float *w = W3p + ((size_t)(ky * 4 + kx) * co_n + co) * c2;
+                const float *pa = a2 + (size_t)s * n2 + (iy * 4 + ix) * c2;
+                const float *pt = ta2 + (size_t)s * n2 + (iy * 4 + ix) * c2;
+                for (int ci = 0; ci < c2; ++ci) {
+                    x = fmaf(pa[ci], w[ci], x);
+                    t = fmaf(pt[ci], w[ci], t);
+                }
+            }
+        }
+        const float sg = 1.0f / (1.0f + expf(-x));
+        const float j = t * sg * (1.0f - sg);
+        jt2[item] = j * j;
+    }
+    __syncthreads();
+    // fixed-order fp64 sum per sample by one wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < BACK_TS; s += 4) {
+        double acc = 0.0;
+        for (int o = lane; o < p_out; o += 64) acc += (double)jt2[s * p_out + o];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) norms[slot0 + s] = (float)sqrt(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ norms, int64_t e_base, int64_t e_count,
+                                                     int batch, int slots_per_group, float *__restrict__ len_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e_count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t chunk = i / batch, within = i % batch;
+        const float a = norms[(chunk * 2 + 0) * slots_per_group + within];
+        const float b = norms[(chunk * 2 + 1) * slots_per_group + within];
+        len_out[e_base + i] = 0.5f * (a + b);
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+bool make_shape(const geo_decoder_desc *dc, Shape *s) {
+    s->d = dc->latent_dim; s->c0 = dc->c0; s->c1 = dc->c1; s->c2 = dc->c2; s->co = dc->out_channels;
+    if (dc->out_size == 28) { s->s_out = 4; s->pad3 = 3; }
+    else if (dc->out_size == 32) { s->s_out = 8; s->pad3 = 1; }
+    else return false;
+    s->p_out = s->co * s->s_out * s->s_out;
+    s->n1 = 4 * s->c1; s->n2 = 16 * s->c2;
+    if (s->c2 <= 0 || NC % s->c2 != 0) return false;
+    s->opix_per_chunk = NC / s->c2;
+    if (s->opix_per_chunk > 16) s->opix_per_chunk = 16;
+    s->n_chunks = 16 / s->opix_per_chunk;
+    return true;
+}
+
+// Output pixels ordered so that neighbours in the list are fed by the same input pixels.
+void make_chunks(const Shape &s, ChunkTable *t) {
+    static const int order[16][2] = {{0, 1}, {0, 2}, {3, 1}, {3, 2}, {1, 0}, {2, 0}, {1, 3}, {2, 3},
+                                     {1, 1}, {1, 2}, {2, 1}, {2, 2}, {0, 0}, {0, 3}, {3, 0}, {3, 3}};
+    for (int ch = 0; ch < 16; ++ch) { t->nblk[ch] = 0; for (int i = 0; i < 16; ++i) t->opix[ch][i] = 0; }
+    for (int ch = 0; ch < s.n_chunks; ++ch) {
+        bool used[4] = {false, false, false, false};
+        for (int lo = 0; lo < s.opix_per_chunk; ++lo) {
+            const int oy = order[ch * s.opix_per_chunk + lo][0], ox = order[ch * s.opix_per_chunk + lo][1];
+            t->opix[ch][lo] = oy * 4 + ox;
+            for (int iy = 0; iy < 2; ++iy)
+                for (int ix = 0; ix < 2; ++ix) {
+                    const int ky = oy + 1 - 2 * iy, kx = ox + 1 - 2 * ix;
+                    if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) used[iy * 2 + ix] = true;
+                }
+        }
+        for (int ip = 0; ip < 4; ++ip)
+            if (used[ip]) t->ipix[ch][t->nblk[ch]++] = ip;
+    }
+}
+
+struct Plan {
+    Shape sh;
+    int batch, tiles_per_group, slots_per_group;
+    int64_t chunks_per_pass;
+    size_t bytes;
+};
+
+constexpr int64_t MAX_SLOTS_PER_PASS = 1 << 21;      // bounds the activation workspace (~25 GB at the shipped sizes)
+
+bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) {
+    if (!make_shape(dc, &p->sh)) return false;
+    p->batch = batch;
+    p->tiles_per_group = (batch + TS - 1) / TS;
+    p->slots_per_group = p->tiles_per_group * TS;
+    const int64_t chunks = (n_edges + batch - 1) / batch;
+    int64_t cpp = MAX_SLOTS_PER_PASS / (2 * (int64_t)p->slots_per_group);
+    if (cpp < 1) cpp = 1;
+    if (cpp > chunks) cpp = chunks > 0 ? chunks : 1;
+    p->chunks_per_pass = cpp;
+    const Shape &s = p->sh;
+    const size_t slots = (size_t)cpp * 2 * p->slots_per_group, tiles = slots / TS, groups = (size_t)cpp * 2;
+    size_t b = 0;
+    b += geo::align_up((size_t)s.d * s.n1 * 4) + geo::align_up((size_t)s.n1 * 4);          // M01, b01
+    b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
+    b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
+    b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
+    b += geo::align_up(tiles * s.n1 * 4 * 8) + geo::align_up(tiles * s.n2 * 4 * 8);         // partial sums
+    b += geo::align_up((groups + 1) * s.c1 * sizeof(NormConst)) + geo::align_up((groups + 1) * s.c2 * sizeof(NormConst));
+    b += geo::align_up(slots * 4) * 2;                                                      // norms, slot_valid
+    p->bytes = b + 4096;
+    return true;
+}
+
+int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, const int32_t *dst, const float *z_start,
+            const float *z_end, int64_t n_edges, int32_t batch, float *len_out, void *ws, size_t ws_bytes,
+            hipStream_t stream) {
+    GEO_REQUIRE(dc && len_out && ws, "geo_decoder_jvp: null pointer");
+    GEO_REQUIRE(batch > 0, "geo_decoder_jvp: batch_size must be positive");
+    if (n_edges == 0) return GEO_OK;
+    Plan pl;
+    GEO_REQUIRE(make_plan(dc, n_edges, batch, &pl),
+                "geo_decoder_jvp: unsupported decoder (out_size %d, c2=%d must divide %d)", dc->out_size, dc->c2, NC);
+    const Shape &s = pl.sh;
+    GEO_REQUIRE(s.d >= 1 && s.d <= 64, "geo_decoder_jvp: latent_dim %d not in [1,64]", s.d);
+    GEO_REQUIRE(s.c1 == 128 || s.c1 == 64 || s.c1 == 32, "geo_decoder_jvp: dec_channels[1]=%d not in {32,64,128}", s.c1);
+    GEO_REQUIRE(dc->norm == 0 || dc->norm == 1, "geo_decoder_jvp: norm_type 'group' is not implemented in the HIP path");
+    const size_t back_lds = ((size_t)2 * BACK_TS * s.n2 + (size_t)BACK_TS * s.p_out) * 4;
+    GEO_REQUIRE(back_lds <= 160 * 1024, "geo_decoder_jvp: decoder too wide for the back kernel (%zu B LDS)", back_lds);
+    if (ws_bytes < pl.bytes) {
+        geo::set_error("geo_decoder_jvp: workspace %zu < %zu", ws_bytes, pl.bytes);
+        return GEO_E_WORKSPACE;
+    }
+    const size_t slots = (size_t)pl.chunks_per_pass * 2 * pl.slots_per_group, tiles = slots / TS;
+    const size_t groups = (size_t)pl.chunks_per_pass * 2;
+    geo::Arena ar(ws, ws_bytes);
+    float *M01 = ar.take<float>((size_t)s.d * s.n1);
+    float *b01 = ar.take<float>((size_t)s.n1);
+    float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
+    float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
+    float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
+    float *pre2 = ar.take<float>(slots * s.n2), *tpre2 = ar.take<float>(slots * s.n2);
+    double *part1 = ar.take<double>(tiles * s.n1 * 4), *part2 = ar.take<double>(tiles * s.n2 * 4);
+    NormConst *k1 = ar.take<NormConst>((groups + 1) * s.c1), *k2 = ar.take<NormConst>((groups + 1) * s.c2);
+    float *norms = ar.take<float>(slots);
+    int32_t *slot_valid = ar.take<int32_t>(slots);
+    GEO_REQUIRE(slot_valid != nullptr, "geo_decoder_jvp: workspace carve failed");
+
+    ChunkTable tab;
+    make_chunks(s, &tab);
+    compose_front_kernel<<<geo::grid_for((int64_t)(s.d + 1) * s.n1, 256), 256, 0, stream>>>(
+        dc->w_in, dc->b_in, dc->w1, dc->b1, s.d, s.c0, s.c1, M01, b01);
+    GEO_LAUNCH_CHECK();
+    pack_mid_kernel<<<geo::grid_for((int64_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC, 256), 256, 0, stream>>>(
+        dc->w2, s.c1, s.c2, tab, s.n_chunks, s.opix_per_chunk, B2p);
+    GEO_LAUNCH_CHECK();
+    pack_back_kernel<<<geo::grid_for(16 * s.co * s.c2, 256), 256, 0, stream>>>(dc->w3, s.c2, s.co, W3p);
+    GEO_LAUNCH_CHECK();
+
+    const bool batch_stats = dc->norm == 1 && dc->bn_train;
+    if (!batch_stats) {
+        finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c1, dc->norm, dc->g1, dc->be1, dc->rm1, dc->rv1, dc->eps, k1);
+        GEO_LAUNCH_CHECK();
+        finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c2, dc->norm, dc->g2, dc->be2, dc->rm2, dc->rv2, dc->eps, k2);
+        GEO_LAUNCH_CHECK();
+    }
+    const int64_t total_chunks = (n_edges + batch - 1) / batch;
+    for (int64_t c0 = 0; c0 < total_chunks; c0 += pl.chunks_per_pass) {
+        int64_t nch = total_chunks - c0;
+        if (nch > pl.chunks_per_pass) nch = pl.chunks_per_pass;
+        const int64_t e_base = c0 * batch;
+        int64_t e_count = n_edges - e_base;
+        if (e_count > nch * batch) e_count = nch * batch;
+        const int64_t p_groups = nch * 2, p_tiles = p_groups * pl.tiles_per_group, p_slots = p_tiles * TS;
+        slot_valid_kernel<<<geo::grid_for(p_slots, 256), 256, 0, stream>>>(e_base, n_edges, batch, pl.tiles_per_group,
+                                                                          p_slots, slot_valid);
+        GEO_LAUNCH_CHECK();
+#define GEO_FRONT(DM)                                                                                              \
+    front_kernel<DM><<<(unsigned)p_tiles, 256, 0, stream>>>(z, src, dst, z_start, z_end, e_base, n_edges, batch,    \
+                                                            pl.tiles_per_group, s.d, s.n1, M01, b01, pre1, tpre1,   \
+                                                            part1, batch_stats ? 1 : 0)
+        if (s.d <= 16) GEO_FRONT(16);
+        else if (s.d <= 32) GEO_FRONT(32);
+        else GEO_FRONT(64);
+#undef GEO_FRONT
+        GEO_LAUNCH_CHECK();
+        if (batch_stats) {
+            finalize_batch_kernel<<<geo::grid_for(p_groups * s.c1, 256), 256, 0, stream>>>(
+                part1, pl.tiles_per_group, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups);
+            GEO_LAUNCH_CHECK();
+        }
+        const dim3 mgrid((unsigned)p_tiles, (unsigned)s.n_chunks);
+#define GEO_MID(C1V)                                                                                               \
+    mid_kernel<C1V><<<mgrid, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, tab,       \
+                                               s.opix_per_chunk, s.c2, B2p, dc->b2, pre2, tpre2, part2,             \
+                                               batch_stats ? 1 : 0, slot_valid)
+        if (s.c1 == 128) GEO_MID(128);
+        else if (s.c1 == 64) GEO_MID(64);
+        else GEO_MID(32);
+#undef GEO_MID
+        GEO_LAUNCH_CHECK();
+        if (batch_stats) {
+            finalize_batch_kernel<<<geo::grid_for(p_groups * s.c2, 256), 256, 0, stream>>>(
+                part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups);
+            GEO_LAUNCH_CHECK();
+        }
+        back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
+            pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);
+        GEO_LAUNCH_CHECK();
+        combine_kernel<<<geo::grid_for(e_count, 256), 256, 0, stream>>>(norms, e_base, e_count, batch,
+                                                                        pl.slots_per_group, len_out);
+        GEO_LAUNCH_CHECK();
+    }
+    return GEO_OK;
+}
+
+}  // namespace
+
+extern "C" size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size) {
+    Plan pl;
+    if (!dec || batch_size <= 0 || n_edges < 0 || !make_plan(dec, n_edges, batch_size, &pl)) return 0;
+    return pl.bytes;
+}
+
+extern "C" int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes, const int32_t *src,
+                                     const int32_t *dst, int64_t n_edges, int32_t batch_size, float *len_out, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    GEO_REQUIRE(n_edges == 0 || (z && src && dst && n_nodes > 0), "geo_decoder_jvp_edges: null pointer");
+    return run_jvp(dec, z, src, dst, nullptr, nullptr, n_edges, batch_size, len_out, ws, ws_bytes,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int geo_decoder_jvp_pairs(const geo_decoder_desc *dec, const float *z_start, const float *z_end,
+                                     int64_t n_edges, int32_t batch_size, float *len_out, void *ws, size_t ws_bytes,
+                                     void *stream) {
+    GEO_REQUIRE(n_edges == 0 || (z_start && z_end), "geo_decoder_jvp_pairs: null pointer");
+    return run_jvp(dec, nullptr, nullptr, nullptr, z_start, z_end, n_edges, batch_size, len_out, ws, ws_bytes,
+                   static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,251 @@
+"""k-NN graph construction on the MI355X -- same API as the reference's
+src/geo/knn_graph_optimized.py (build_knn_graph_sklearn :25, build_knn_graph_faiss :70,
+build_knn_graph_auto :129, largest_connected_component :173, analyze_graph_connectivity :184,
+build_knn_graph :223).
+
+The neighbour search (sklearn / FAISS in the reference) is the exact fp64-ranked brute force of
+csrc/knn.hip; the CSR assembly, union / mutual symmetrisation, diagonal and zero removal run in
+csrc/graph.hip, as do connected components.  Results are returned as the same host objects
+(scipy.sparse.csr_matrix float32, numpy arrays).
+"""
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from .. import _lib
+from .._device import DeviceCSR, device, ptr, stream_ptr, workspace
+
+_SYM_MODE = {"union": 0, "mutual": 1}
+MAX_NEIGHBORS = 64          # n_neighbors (k + 1) supported by the wave-resident top-k list
+
+
+# --------------------------------------------------------------------------------- device level
+def knn_search_device(z: torch.Tensor, n_neighbors: int, row0: int = 0, row1: Optional[int] = None):
+    """(idx int32 [rows, n_neighbors], d2 float64 [rows, n_neighbors]) sorted by (distance, index),
+    self included, for query rows [row0, row1) of the resident latents z (f32 [N, d])."""
+    lib = _lib.load()
+    N, d = z.shape
+    row1 = N if row1 is None else row1
+    if n_neighbors > MAX_NEIGHBORS:
+        raise ValueError(f"k + 1 = {n_neighbors} neighbours exceed the supported maximum of {MAX_NEIGHBORS}")
+    if d > 128:
+        raise ValueError(f"latent dimension {d} exceeds the supported maximum of 128")
+    idx = torch.empty((row1 - row0, n_neighbors), dtype=torch.int32, device=z.device)
+    d2 = torch.empty((row1 - row0, n_neighbors), dtype=torch.float64, device=z.device)
+    ws = workspace(lib.geo_knn_workspace_bytes(N, d), z.device)
+    form = 1 if d > 15 else 0           # sklearn "auto": brute-force expansion above 15 dims, kd-tree below
+    with torch.cuda.device(z.device):
+        _lib.check(lib.geo_knn_topk(ptr(z), N, d, n_neighbors, form, row0, row1, ptr(idx), ptr(d2), ptr(ws),
+                                    ws.numel(), stream_ptr()), "geo_knn_topk")
+    return idx, d2
+
+
+def symmetrize_device(nbr_idx: torch.Tensor, nbr_w: Optional[torch.Tensor], sym: str) -> DeviceCSR:
+    """Directed neighbour lists (int32 [N,k], optional f32 weights) -> canonical symmetric CSR."""
+    lib = _lib.load()
+    n, k = nbr_idx.shape
+    dev = nbr_idx.device
+    ws = workspace(lib.geo_symmetrize_workspace_bytes(n, k), dev)
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nnz = np.zeros(1, dtype=np.int64)
+    mode = _SYM_MODE[sym]
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_symmetrize_count(ptr(nbr_idx), ptr(nbr_w), n, k, mode, ptr(indptr), nnz.ctypes.data,
+                                            ptr(ws), ws.numel(), stream_ptr()), "geo_symmetrize_count")
+        indices = torch.empty(int(nnz[0]), dtype=torch.int32, device=dev)
+        data = torch.empty(int(nnz[0]), dtype=torch.float32, device=dev)
+        _lib.check(lib.geo_symmetrize_fill(ptr(nbr_idx), ptr(nbr_w), n, k, mode, ptr(indptr), ptr(indices), ptr(data),
+                                           ptr(ws), ws.numel(), stream_ptr()), "geo_symmetrize_fill")
+    return DeviceCSR(n, indptr, indices, data)
+
+
+def _drop_self(dist: torch.Tensor, idx: torch.Tensor):
+    """knn_graph_optimized.py:45-52 on device tensors."""
+    N = idx.shape[0]
+    me = torch.arange(N, device=idx.device, dtype=idx.dtype)
+    if bool((idx[:, 0] == me).all()):
+        return dist[:, 1:].contiguous(), idx[:, 1:].contiguous()
+    # duplicates put another point in front of self somewhere: drop each row's first minimum (rare path,
+    # done with numpy's first-index argmin on the host to keep its tie rule)
+    dist_h, idx_h = dist.cpu().numpy(), idx.cpu().numpy()
+    keep = np.ones(idx_h.shape, dtype=bool)
+    keep[np.arange(N), np.argmin(dist_h, axis=1)] = False
+    dist_k = torch.from_numpy(dist_h[keep].reshape(N, -1)).to(dist.device)
+    idx_k = torch.from_numpy(idx_h[keep].reshape(N, -1)).to(idx.device)
+    return dist_k.contiguous(), idx_k.contiguous()
+
+
+def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual"):
+    """Resident latents -> (DeviceCSR, distances f64 [N,k'], indices int32 [N,k']); k' = min(k, N-1) >= 1."""
+    if sym not in _SYM_MODE:
+        raise ValueError(f"Invalid symmetry mode: {sym}")
+    N = z.shape[0]
+    k_eff = max(0, min(k, N - 1))
+    idx, d2 = knn_search_device(z, min(k_eff + 1, N))
+    dist, idx = _drop_self(torch.sqrt(d2), idx)
+    weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
+    return symmetrize_device(idx, weights, sym), dist, idx
+
+
+def connected_components_device(G: DeviceCSR):
+    """(n_components, labels int32 on device) for a structurally symmetric resident graph."""
+    lib = _lib.load()
+    dev = G.indptr.device
+    labels = torch.empty(G.n, dtype=torch.int32, device=dev)
+    ncomp = np.zeros(1, dtype=np.int32)
+    ws = workspace(lib.geo_cc_workspace_bytes(G.n), dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_connected_components(ptr(G.indptr), ptr(G.indices), G.n, ptr(labels), ncomp.ctypes.data,
+                                                ptr(ws), ws.numel(), stream_ptr()), "geo_connected_components")
+    return int(ncomp[0]), labels
+
+
+def lcc_mask_device(G: DeviceCSR) -> torch.Tensor:
+    """Boolean mask (device) of the largest component; first label on ties (np.argmax of bincount)."""
+    ncomp, labels = connected_components_device(G)
+    if ncomp <= 1:
+        return torch.ones(G.n, dtype=torch.bool, device=G.indptr.device)
+    counts = torch.bincount(labels.long(), minlength=ncomp).cpu().numpy()
+    return labels == int(np.argmax(counts))
+
+
+def compact_device(G: DeviceCSR, keep: Optional[torch.Tensor], drop_zero: bool) -> Tuple[DeviceCSR, torch.Tensor]:
+    """Sub-graph on the kept nodes (W[mask][:, mask]) without zero-weight entries; also the old->new index map."""
+    lib = _lib.load()
+    dev = G.indptr.device
+    ws = workspace(lib.geo_csr_compact_workspace_bytes(G.n), dev)
+    keep_u8 = None if keep is None else keep.to(torch.uint8).contiguous()
+    new_index = torch.empty(G.n, dtype=torch.int32, device=dev)
+    indptr_new = torch.empty(G.n + 1, dtype=torch.int32, device=dev)
+    n_new, nnz_new = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int64)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_csr_compact_count(ptr(G.indptr), ptr(G.indices), ptr(G.data), G.n, ptr(keep_u8),
+                                             1 if drop_zero else 0, ptr(new_index), ptr(indptr_new),
+                                             n_new.ctypes.data, nnz_new.ctypes.data, ptr(ws), ws.numel(),
+                                             stream_ptr()), "geo_csr_compact_count")
+        indices = torch.empty(int(nnz_new[0]), dtype=torch.int32, device=dev)
+        data = torch.empty(int(nnz_new[0]), dtype=torch.float32, device=dev)
+        if int(n_new[0]) > 0:
+            _lib.check(lib.geo_csr_compact_fill(ptr(G.indptr), ptr(G.indices), ptr(G.data), G.n, ptr(keep_u8),
+                                                1 if drop_zero else 0, ptr(new_index), ptr(indptr_new), ptr(indices),
+                                                ptr(data), stream_ptr()), "geo_csr_compact_fill")
+    n = int(n_new[0])
+    return DeviceCSR(n, indptr_new[: n + 1].contiguous(), indices, data), new_index
+
+
+def upper_edges_device(G: DeviceCSR):
+    """(src, dst int32 [E], entry_edge int32 [nnz]): stored entries with row < col in row-major order
+    (build_codebook.py:43-45) and, for every entry, the index of its undirected edge."""
+    lib = _lib.load()
+    dev = G.indptr.device
+    ws = workspace(lib.geo_cc_workspace_bytes(G.n), dev)
+    upper_ptr = torch.empty(G.n + 1, dtype=torch.int32, device=dev)
+    n_edges = np.zeros(1, dtype=np.int64)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_upper_edges_count(ptr(G.indptr), ptr(G.indices), G.n, ptr(upper_ptr), n_edges.ctypes.data,
+                                             ptr(ws), ws.numel(), stream_ptr()), "geo_upper_edges_count")
+        E = int(n_edges[0])
+        src = torch.empty(E, dtype=torch.int32, device=dev)
+        dst = torch.empty(E, dtype=torch.int32, device=dev)
+        entry_edge = torch.empty(G.nnz, dtype=torch.int32, device=dev)
+        _lib.check(lib.geo_upper_edges_fill(ptr(G.indptr), ptr(G.indices), G.n, ptr(upper_ptr), ptr(src), ptr(dst),
+                                            ptr(entry_edge), stream_ptr()), "geo_upper_edges_fill")
+    return src, dst, entry_edge
+
+
+def reweight_device(G: DeviceCSR, entry_edge: torch.Tensor, lengths: torch.Tensor) -> DeviceCSR:
+    """W_geo = U + U^T (build_codebook.py:53-54): every stored entry takes its edge's length."""
+    lib = _lib.load()
+    data = torch.empty(G.nnz, dtype=torch.float32, device=G.indptr.device)
+    with torch.cuda.device(G.indptr.device):
+        _lib.check(lib.geo_gather_edge_weights(ptr(lengths), ptr(entry_edge), G.nnz, ptr(data), stream_ptr()),
+                   "geo_gather_edge_weights")
+    return DeviceCSR(G.n, G.indptr, G.indices, data)
+
+
+# --------------------------------------------------------------------------------- reference API
+def _empty_result(N: int):
+    W = sparse.csr_matrix((N, N), dtype=np.float32)
+    return W, {"distances": np.empty((N, 0), np.float32), "indices": np.empty((N, 0), dtype=int)}
+
+
+def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
+                            sym: str = "mutual") -> Tuple[sparse.csr_matrix, Dict[str, np.ndarray]]:
+    """Exact k-NN graph (the reference's scikit-learn builder, knn_graph_optimized.py:25-67), computed on the GPU."""
+    assert z.ndim == 2, "z must be (N,D)"
+    N = z.shape[0]
+    if N == 0:
+        return (sparse.csr_matrix((0, 0), dtype=np.float32),
+                {"distances": np.empty((0, 0), np.float32), "indices": np.empty((0, 0), dtype=int)})
+    if max(0, min(k, N - 1)) == 0:
+        return _empty_result(N)
+    if metric != "euclidean":
+        raise ValueError(f"metric '{metric}' is not supported by the HIP k-NN kernel (euclidean only)")
+    if sym not in _SYM_MODE:
+        raise ValueError(f"Invalid symmetry mode: {sym}")
+    dev = device()
+    z_dev = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).to(dev)
+    G, dist, idx = knn_graph_device(z_dev, k, mode=mode, sym=sym)
+    info = {"distances": dist.to(torch.float32).cpu().numpy(), "indices": idx.cpu().numpy().astype(np.int64)}
+    return G.to_scipy(), info
+
+
+def build_knn_graph_faiss(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
+                          sym: str = "mutual"):
+    """FAISS is not part of this build; same error the reference raises without it (knn_graph_optimized.py:73-74)."""
+    raise RuntimeError("FAISS not available, falling back to sklearn")
+
+
+def build_knn_graph_auto(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
+                         sym: str = "mutual", force_method: Optional[str] = None, size_threshold: int = 50000):
+    """Method selection kept for signature compatibility (knn_graph_optimized.py:129-170); every size runs the
+    exact HIP brute force."""
+    if force_method == "faiss":
+        raise RuntimeError("force_method='faiss' but FAISS not available")
+    print(f"Building k-NN graph: N={z.shape[0]}, k={k}, method=hip")
+    return build_knn_graph_sklearn(z, k=k, metric=metric, mode=mode, sym=sym)
+
+
+def _undirected_structure(W: sparse.spmatrix, dev) -> DeviceCSR:
+    """Stored pattern of W made symmetric (connected_components(directed=False) uses edges both ways)."""
+    W = sparse.csr_matrix(W)
+    P = sparse.csr_matrix((np.ones(W.nnz, np.float32), W.indices, W.indptr), shape=W.shape)
+    S = (P + P.T).tocsr()
+    S.sort_indices()
+    return DeviceCSR.from_scipy(S, dev, with_data=False)
+
+
+def largest_connected_component(W: sparse.csr_matrix) -> np.ndarray:
+    """Boolean mask of the nodes in the largest connected component (knn_graph_optimized.py:173-181)."""
+    if W.shape[0] == 0:
+        return np.ones(0, dtype=bool)
+    return lcc_mask_device(_undirected_structure(W, device())).cpu().numpy()
+
+
+def analyze_graph_connectivity(W: sparse.csr_matrix) -> Dict:
+    """Connectivity statistics with the reference's printout (knn_graph_optimized.py:184-219)."""
+    N = W.shape[0]
+    n_components, labels = connected_components_device(_undirected_structure(W, device()))
+    if n_components > 1:
+        largest_size = int(torch.bincount(labels.long()).max())
+        connectivity_ratio = largest_size / N
+    else:
+        largest_size, connectivity_ratio = N, 1.0
+    degrees = np.array(W.sum(axis=1)).flatten()
+    stats = {"n_nodes": N, "n_edges": W.nnz, "n_components": n_components,
+             "largest_component_size": largest_size, "connectivity_ratio": connectivity_ratio,
+             "avg_degree": degrees.mean(), "min_degree": degrees.min(), "max_degree": degrees.max()}
+    print("Graph connectivity")
+    print(f"nodes={N} edges={W.nnz} avg_deg={stats['avg_degree']:.1f}")
+    print(f"components={n_components} largest={largest_size} ({100*connectivity_ratio:.1f}%)")
+    if n_components > 1:
+        print("disconnected -> will use LCC")
+    return stats
+
+
+def build_knn_graph(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
+                    sym: str = "mutual"):
+    """Backward compatible entry point (knn_graph_optimized.py:223-231)."""
+    return build_knn_graph_auto(z, k=k, metric=metric, mode=mode, sym=sym)

@@ -1,0 +1,137 @@
+"""Build a geodesic spatial codebook on the MI355X -- drop-in for the reference CLI
+src/scripts/build_codebook.py (main :14-106, flags :108-134; same flags, same three artefacts).
+
+    python -m vqvae_amd.scripts.build_codebook --latents_path z.pt --out_dir out --vae_ckpt_path best.pt \
+        --in_channels 1 --output_image_size 28 --latent_dim 16 --enc_channels 64 128 256 \
+        --dec_channels 256 128 64 --recon_loss mse --norm_type batch --mse_use_sigmoid \
+        --k 20 --sym union --K 512 --init kpp --seed 42 --batch_size 512
+
+Everything between loading the latents and writing the artefacts stays resident in HBM:
+kNN (csrc/knn.hip) -> symmetric CSR + upper edge list (csrc/graph.hip) -> pull-back edge lengths
+(csrc/jvp.hip) -> largest component + compaction (csrc/graph.hip) -> k-means++ / assignment over
+geodesic distances (csrc/sssp.hip).
+"""
+import argparse
+import time
+from pathlib import Path
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from .._device import DeviceCSR, device
+from ..geo.kmeans_optimized import fit_kmedoids_optimized
+from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
+                                       upper_edges_device)
+from ..geo.riemannian_metric import edge_lengths_graph_device
+from ..spatial_decoder import DecoderExport, load_decoder_from_checkpoint
+
+
+def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: str = "union", K: int = 512,
+                          init: str = "kpp", seed: int = 42, batch_size: int = 512,
+                          timers: Optional[Dict[str, float]] = None) -> dict:
+    """The hot path on resident data.  z_flat: f32 [n_nodes, d] on the GPU, rows in (n, h, w) order.
+    Returns device/host results; `timers` (if given) receives per-stage seconds (synchronised)."""
+    dev = z_flat.device
+
+    def tick(name, t0):
+        if timers is not None:
+            torch.cuda.synchronize(dev)
+            timers[name] = timers.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t0 = time.perf_counter()
+    G, _, _ = knn_graph_device(z_flat, k, mode="connectivity", sym=sym)
+    src, dst, entry_edge = upper_edges_device(G)
+    t0 = tick("knn", t0)
+
+    print(f"Re-weighting {src.numel()} edges using Riemannian metric...")
+    export = DecoderExport(decoder, dev)
+    lengths = edge_lengths_graph_device(export, z_flat, src, dst, batch_size)
+    t0 = tick("jvp", t0)
+
+    W_geo = reweight_device(G, entry_edge, lengths)
+    has_zero = bool((lengths == 0).any())               # U + U^T drops entries that sum to exactly 0
+    if has_zero:
+        W_geo, _ = compact_device(W_geo, None, drop_zero=True)
+    mask = lcc_mask_device(W_geo)
+    n_lcc = int(mask.sum())
+    if n_lcc < W_geo.n:
+        print(f"Using LCC: {n_lcc}/{W_geo.n} nodes")
+        W_lcc, _ = compact_device(W_geo, mask, drop_zero=False)
+        z_lcc = z_flat[mask]
+    else:
+        W_lcc, z_lcc = W_geo, z_flat
+    t0 = tick("lcc", t0)
+
+    medoids, assign_lcc, qe = fit_kmedoids_optimized(W_lcc, K=K, init=init, seed=seed)
+    t0 = tick("kmedoids", t0)
+
+    mask_h = mask.cpu().numpy()
+    assign_flat = np.full(z_flat.shape[0], -1, dtype=np.int32)
+    assign_flat[mask_h] = assign_lcc
+    z_medoid = z_lcc[torch.from_numpy(medoids).to(dev)].cpu()
+    return {"W_lcc": W_lcc, "mask_lcc": mask_h, "medoids": medoids, "assign_flat": assign_flat, "qe": qe,
+            "z_medoid": z_medoid, "n_edges": int(src.numel()), "edge_lengths": lengths, "edges": (src, dst)}
+
+
+def main(args):
+    """Builds a spatial codebook using a geodesic metric and saves artifacts."""
+    out_dir = Path(args.out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    dev = device()
+
+    decoder = load_decoder_from_checkpoint(
+        args.vae_ckpt_path, in_channels=args.in_channels, dec_channels=args.dec_channels,
+        latent_dim=args.latent_dim, output_image_size=args.output_image_size, norm_type=args.norm_type, device=dev)
+
+    z = torch.load(Path(args.latents_path), map_location="cpu").float()
+    N, C, H, W = z.shape
+    print(f"Loaded spatial latents: N={N}, C={C}, H={H}, W={W}")
+    z_flat = z.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
+    print(f"Reshaped to: {tuple(z_flat.shape)}")
+
+    print(f"Building k-NN graph: N={z_flat.shape[0]}, k={args.k}, method=hip")
+    res = build_codebook_device(z_flat, decoder, k=args.k, sym=args.sym, K=args.K, init=args.init, seed=args.seed,
+                                batch_size=args.batch_size)
+
+    sparse.save_npz(out_dir / "knn_graph_geodesic.npz", res["W_lcc"].to_scipy())
+    codes = res["assign_flat"].reshape(N, H, W)
+    codebook = {
+        "medoid_indices": res["medoids"].astype(np.int32),
+        "z_medoid": res["z_medoid"].float(),
+        "config": {key: getattr(args, key) for key in (
+            "latents_path", "out_dir", "vae_ckpt_path", "in_channels", "output_image_size", "latent_dim",
+            "enc_channels", "dec_channels", "recon_loss", "norm_type", "mse_use_sigmoid", "k", "sym", "K", "init",
+            "seed", "batch_size")},
+    }
+    torch.save(codebook, out_dir / "codebook.pt")
+    np.save(out_dir / "codes.npy", codes)
+    print(f"Quantization error: {res['qe']:.3f}")
+    print(f"Saved artifacts to: {out_dir}")
+    return res
+
+
+def make_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description="Build a geodesic spatial codebook.")
+    for name in ("latents_path", "out_dir", "vae_ckpt_path"):
+        parser.add_argument(f"--{name}", type=str, required=True)
+    for name in ("in_channels", "output_image_size", "latent_dim"):
+        parser.add_argument(f"--{name}", type=int, required=True)
+    parser.add_argument("--enc_channels", type=int, nargs='+', required=True)
+    parser.add_argument("--dec_channels", type=int, nargs='+', required=True)
+    parser.add_argument("--recon_loss", type=str, required=True)
+    parser.add_argument("--norm_type", type=str, required=True)
+    parser.add_argument("--mse_use_sigmoid", action='store_true')
+    parser.add_argument("--k", type=int, default=20)
+    parser.add_argument("--sym", type=str, default="union")
+    parser.add_argument("--K", type=int, default=512)
+    parser.add_argument("--init", type=str, default="kpp")
+    parser.add_argument("--seed", type=int, default=42)
+    parser.add_argument("--batch_size", type=int, default=512)
+    return parser
+
+
+if __name__ == "__main__":
+    main(make_parser().parse_args())
