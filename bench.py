@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- latents/s through the geodesic-codebook hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of synthetic latents already resident in HBM
+(BASELINE.json configs[1]: 60 000 latents, d=16, k=20, K=512, FashionMNIST-shaped decoder with
+train-mode BatchNorm as the reference CLI leaves it):
+    kNN graph -> upper edge list -> decoder pull-back edge lengths -> LCC -> k-means++ chain
+    (K single-source solves with fused running argmin) -> the reference's assignment stage
+    (K-source batched solve + column argmin = the "APSP + K-medoids sweep" of BASELINE.json).
+Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...); everything else goes to stderr.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use (the GPU box gives a 1-GPU job a share of the host)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("GEO_BENCH_CPU_THREADS", "16"))))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))      # before numpy/torch/OpenMP start their pools
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_latents, d, out_channels, image_size, k, K)
+    "c1": (2048, 16, 1, 28, 20, 64),
+    "c2": (60000, 16, 1, 28, 20, 512),
+    "c3": (50000, 32, 3, 32, 20, 512),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(name, dev):
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    n, d, cout, size, k, K = WORKLOADS[name]
+    z = torch.from_numpy(np.random.RandomState(0).randn(n, d).astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    dec = SpatialDecoder(cout, (256, 128, 64), d, size, "batch").to(dev).train()    # random init, BN in train mode
+    return z, dec, dict(n=n, d=d, k=k, K=K, size=size, cout=cout)
+
+
+def hot_path_step(z, dec, cfg, timers, rank, world):
+    """One full pass; returns (result dict, sweep profile)."""
+    from vqvae_amd import _lib
+    from vqvae_amd.geo.geo_shortest_paths import sssp_multi_device
+    from vqvae_amd.scripts.build_codebook import build_codebook_device
+    res = build_codebook_device(z, dec, k=cfg["k"], sym="union", K=cfg["K"], init="kpp", seed=42, batch_size=512,
+                                timers=timers)
+    t0 = time.perf_counter()
+    G = res["W_lcc"]
+    src = torch.from_numpy(res["medoids"].astype(np.int32)).to(z.device)
+    _, _, dmin, arg, sweeps = sssp_multi_device(G, src, want_D=False, want_min=True)
+    ms, launches = np.zeros(1, np.float64), np.zeros(1, np.int32)
+    _lib.load().geo_sssp_last_profile(ms.ctypes.data, launches.ctypes.data)
+    torch.cuda.synchronize(z.device)
+    timers["assign_sweep"] = timers.get("assign_sweep", 0.0) + time.perf_counter() - t0
+    res["assign_batched"] = arg
+    return res, (float(ms[0]), int(launches[0]))
+
+
+def cpu_baseline(res, z, dec, cfg):
+    """The oracle (CPU restatement, validated against the reference in the build container) timed on this
+    host on a bounded sample and scaled to the full workload with the reference's solve count (3K-1)."""
+    from oracle import _clib, metric as om, sssp as osp
+    import ctypes
+    n, d, K = cfg["n"], cfg["d"], cfg["K"]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    zh = np.ascontiguousarray(z.cpu().numpy())
+    lib = _clib.lib()
+    rows = min(n, 6000)
+    idx = np.empty((rows, cfg["k"] + 1), np.int64)
+    d2 = np.empty((rows, cfg["k"] + 1), np.float64)
+    t0 = time.perf_counter()
+    lib.oracle_knn(ctypes.c_void_p(zh.ctypes.data), n, d, cfg["k"] + 1, 1 if d > 15 else 0, 0, rows,
+                   ctypes.c_void_p(idx.ctypes.data), ctypes.c_void_p(d2.ctypes.data))
+    t_knn = (time.perf_counter() - t0) * n / rows
+    src, dst = (t.cpu().numpy() for t in res["edges"])
+    E = len(src)
+    e_s = min(E, 8192)
+    sd = {k_: v.detach().cpu() for k_, v in dec.state_dict().items()}
+    t0 = time.perf_counter()
+    om.edge_lengths(sd, "batch", cfg["size"], zh[src[:e_s]], zh[dst[:e_s]], batch_size=512, training=True)
+    t_jvp = (time.perf_counter() - t0) * E / e_s
+    W = res["W_lcc"].to_scipy()
+    n_src = 24
+    t0 = time.perf_counter()
+    osp.dijkstra_multi_source(W, res["medoids"][:n_src])
+    t_solve = (time.perf_counter() - t0) / min(n_src, len(res["medoids"]))
+    t_kmed = t_solve * (3 * K - 1)
+    total = t_knn + t_jvp + t_kmed
+    return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle on host: kNN {rows}/{n} query rows x{n / rows:.0f}, JVP {e_s}/{E} edges x{E / e_s:.0f} "
+                       f"(torch CPU, {cores} threads), Dijkstra {n_src} sources x{(3 * K - 1) / n_src:.0f} "
+                       f"(reference runs 3K-1 = {3 * K - 1} single-thread solves)"),
+            "stages_s": {"knn": round(t_knn, 3), "jvp": round(t_jvp, 3), "kmedoids": round(t_kmed, 3)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    z, dec, cfg = make_inputs(args.workload, dev)
+    timers, prof, res = {}, (0.0, 0), None
+    with contextlib.redirect_stdout(sys.stderr):
+        for _ in range(args.warmup):
+            res, prof = hot_path_step(z, dec, cfg, {}, rank, world)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res, prof = hot_path_step(z, dec, cfg, timers, rank, world)
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the batched assignment stage must reproduce the fused chain's assignment
+    same = bool((res["assign_batched"].cpu().numpy() == res["assign_flat"][res["mask_lcc"]]).all())
+    G = res["W_lcc"]
+    n, nnz, K = G.n, G.nnz, len(res["medoids"])
+    sweep_ms, launches = prof
+    algo_bytes = K * (16.0 * nnz + 16.0 * n)            # B_sssp per source x K sources
+    achieved = algo_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("sweep_multi_hbm_bytes_per_launch")
+    ms_per_step = elapsed / args.steps * 1e3
+    # every rank runs the whole workload (replicas) until the sharded path lands: per-rank latents x ranks
+    out = {
+        "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] * world / (elapsed / args.steps),
+        "unit": "latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: N={cfg['n']} latents d={cfg['d']} k={cfg['k']} K={cfg['K']} "
+                               f"{cfg['size']}px decoder BN-train batch 512 sym=union init=kpp seed=42",
+                   "graph": {"nodes": n, "nnz": nnz, "edges_reweighted": res["n_edges"]},
+                   "parallelism": f"replicas x{world}" if world > 1 else "1 gpu"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "sweep_multi_kernel", "launches_per_step": launches,
+                     "avg_launch_ms": sweep_ms / max(1, launches),
+                     "algorithmic_bytes_per_launch": algo_bytes / max(1, launches)},
+        "stages_ms": {k_: v * 1e3 / args.steps for k_, v in timers.items()},
+        "parity_selfcheck": {"batched_assign_equals_fused": same, "qe": res["qe"]},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            with contextlib.redirect_stdout(sys.stderr):
+                out["cpu_baseline"] = cpu_baseline(res, z, dec, cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

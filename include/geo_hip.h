@@ -59,6 +59,10 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
                    float *D_out, int32_t *P_out, float *dmin_out, int32_t *argmin_out,
                    void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 
+/* Device time (ms, HIP events on the call's stream) spent in the relaxation sweeps of the last
+ * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline. */
+int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
+
 /* One source; fused k-means++ bookkeeping of kmeans_optimized.py:43-44 and the single-pass
  * assignment: d32 = f32(dist(source, .)); where d32 < dmin: dmin = d32, argmin = center_pos.
  * d_out f32 [n] may be NULL, dmin_inout/argmin_inout may be NULL.  Synchronises. */

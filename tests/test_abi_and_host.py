@@ -1,0 +1,191 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/geo_hip.h declares, the host
+logic of the reference-API wrappers (validation, pull structure, k-means++ draw, decoder export, CLI flags)
+and the rule that the product never touches oracle/ and fails loudly without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "geo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(geo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    assert sorted(_lib.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.geo_version() >= 100
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (geo_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+
+
+def test_abi_has_no_torch_types():
+    text = open(os.path.join(ROOT, "include", "geo_hip.h")).read()
+    assert 'extern "C"' in text
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)           # signatures only, comments stripped
+    assert "torch" not in code.lower() and "at::" not in code and "Tensor" not in code
+
+
+def test_product_never_imports_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "vqvae_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "liboracle" not in src, f
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    from vqvae_amd import _lib
+    from vqvae_amd.geo import build_knn_graph, dijkstra_multi_source
+    W = sparse.csr_matrix((np.ones(2, np.float32), ([0, 1], [1, 0])), shape=(2, 2))
+    with pytest.raises(_lib.GeoHipError):
+        dijkstra_multi_source(W, [0])
+    with pytest.raises(_lib.GeoHipError):
+        build_knn_graph(np.random.RandomState(0).randn(10, 4).astype(np.float32), k=3)
+
+
+def test_validation_errors_match_reference_classes():
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, distances_between, ensure_valid_graph
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
+    W = sparse.csr_matrix((np.ones(2, np.float32), ([0, 1], [1, 0])), shape=(2, 2))
+    with pytest.raises(TypeError):
+        ensure_valid_graph(np.zeros((3, 3)))
+    with pytest.raises(ValueError):
+        ensure_valid_graph(sparse.csr_matrix((3, 4)))
+    Wn = W.copy()
+    Wn.data[0] = -1
+    with pytest.raises(ValueError):
+        ensure_valid_graph(Wn)
+    assert sparse.isspmatrix_csr(ensure_valid_graph(W.tocoo()))
+    with pytest.raises(ValueError):
+        dijkstra_multi_source(W, [])
+    with pytest.raises(ValueError):
+        distances_between(W, [0], [])
+    with pytest.raises(ValueError):
+        fit_kmedoids_optimized(W, K=1, init="bogus")
+
+
+def test_knn_host_special_cases_need_no_gpu():
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph, build_knn_graph_auto
+    W, nb = build_knn_graph(np.empty((0, 8), np.float32), k=10)
+    assert W.shape == (0, 0) and nb["distances"].shape == (0, 0) and nb["indices"].shape == (0, 0)
+    W, nb = build_knn_graph(np.zeros((1, 8), np.float32), k=10)
+    assert W.shape == (1, 1) and nb["indices"].shape == (1, 0)
+    W, nb = build_knn_graph(np.zeros((25, 4), np.float32), k=0)
+    assert W.nnz == 0 and nb["indices"].shape == (25, 0) and W.dtype == np.float32
+    with pytest.raises(RuntimeError):
+        build_knn_graph_auto(np.zeros((5, 2), np.float32), k=1, force_method="faiss")
+    with pytest.raises(AssertionError):
+        build_knn_graph(np.zeros(4, np.float32))
+
+
+def test_pull_structure():
+    from vqvae_amd.geo.geo_shortest_paths import _pull_structure
+    W = sparse.csr_matrix((np.array([5.0, 1.0, 2.0], np.float32), ([0, 1, 2], [1, 0, 0])), shape=(3, 3))
+    G = _pull_structure(W, directed=True)                   # row v = edges into v
+    assert G[1, 0] == 5.0 and G[0, 1] == 1.0 and G[0, 2] == 2.0 and G.nnz == 3
+    U = _pull_structure(W, directed=False)                  # both directions, duplicates kept as parallel edges
+    assert U.indptr[-1] == 6
+    rows = np.repeat(np.arange(3), np.diff(U.indptr))
+    pairs = sorted(zip(rows, U.indices, U.data))
+    assert pairs == [(0, 1, 1.0), (0, 1, 5.0), (0, 2, 2.0), (1, 0, 1.0), (1, 0, 5.0), (2, 0, 2.0)]
+    S = sparse.csr_matrix((np.ones(2, np.float32), ([0, 1], [1, 0])), shape=(2, 2))
+    assert _pull_structure(S, directed=False) is not None and _pull_structure(S, directed=False).nnz == 2
+
+
+def test_kpp_draw_matches_oracle_draw():
+    from oracle import kmedoids as ok
+    from vqvae_amd.geo.kmeans_optimized import _next_center
+    r = np.random.RandomState(0)
+    d = r.rand(500).astype(np.float32)
+    d[[3, 77]] = np.inf
+    centers = [5, 9]
+    a = _next_center(np.random.RandomState(7), 500, d.copy(), list(centers))
+    probs = ok._seeding_probs(d.copy(), list(centers))
+    b = ok._draw_next(np.random.RandomState(7), 500, probs, list(centers))
+    assert a == b
+    assert _next_center(np.random.RandomState(1), 3, np.zeros(3, np.float32), [0, 1, 2]) is None
+    assert _next_center(np.random.RandomState(1), 3, np.zeros(3, np.float32), [0]) in (1, 2)
+
+
+def test_decoder_module_and_export_on_cpu():
+    from oracle import metric as om
+    from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder, looks_like_spatial_decoder, make_norm
+    for norm, code in (("batch", 1), ("group", 2), ("none", 0)):
+        sd = om.make_decoder_state(1, 16, 1, norm_type=norm)
+        dec = SpatialDecoder(1, (256, 128, 64), 16, 28, norm)
+        dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})      # same key names
+        assert looks_like_spatial_decoder(dec)
+        ex = DecoderExport(dec, torch.device("cpu"))
+        assert (ex.desc.latent_dim, ex.desc.c0, ex.desc.c1, ex.desc.c2, ex.desc.out_channels) == (16, 256, 128, 64, 1)
+        assert ex.desc.out_size == 28 and ex.desc.norm == code
+        assert ex.desc.bn_train == (1 if norm == "batch" else 0)
+        dec.eval()
+        assert DecoderExport(dec, torch.device("cpu")).desc.bn_train == 0
+        # the module computes what the oracle's closed form differentiates
+        x = torch.randn(4, 16, 1, 1)
+        assert dec(x).shape == (4, 1, 4, 4)
+    assert SpatialDecoder(3, (256, 128, 64), 32, 32, "batch")(torch.randn(2, 32, 1, 1)).shape == (2, 3, 8, 8)
+    assert isinstance(make_norm("group", 48), torch.nn.GroupNorm) and make_norm("group", 48).num_groups == 24
+    assert not looks_like_spatial_decoder(torch.nn.Sequential(torch.nn.Linear(4, 4)))
+    with pytest.raises(ValueError):
+        SpatialDecoder(1, (8, 8, 8), 4, 64, "none")
+
+
+def test_generic_decoder_path_on_cpu_matches_reference_properties():
+    """The reference's tests/test_riemannian_metric.py:25-62 on the Linear test decoder (no kernel exists
+    for arbitrary modules: torch.func.jvp on the decoder's own device)."""
+    from vqvae_amd.geo.riemannian_metric import decoder_logits_to_img, edge_lengths_riemannian
+
+    class DummyDec(torch.nn.Module):
+        def __init__(self, d=16, hw=784):
+            super().__init__()
+            self.lin = torch.nn.Linear(d, hw)
+
+        def forward(self, z):
+            return self.lin(z).view(z.size(0), 1, 28, 28)
+
+    dec = DummyDec().eval()
+    g = torch.Generator().manual_seed(42)
+    zi = torch.randn(127, 16, generator=g)
+    zj = zi + 0.1 * torch.randn(127, 16, generator=g)
+    L = edge_lengths_riemannian(dec, zi, zj, batch_size=32)
+    assert L.shape == (127,) and L.dtype == torch.float32 and torch.all(L >= 0)
+    assert torch.allclose(L, edge_lengths_riemannian(dec, zj, zi, batch_size=64), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(edge_lengths_riemannian(dec, zi, zj, batch_size=16),
+                          edge_lengths_riemannian(dec, zi, zj, batch_size=1024), rtol=1e-5, atol=1e-7)
+    Lh = edge_lengths_riemannian(dec, zi, zi + 0.5 * (zj - zi), batch_size=64)
+    assert torch.all(Lh <= L + 1e-6) and 0.3 < (Lh / (L + 1e-8)).mean().item() < 0.7
+    with pytest.raises(AssertionError):
+        edge_lengths_riemannian(dec, zi, zj[:5])
+    assert torch.equal(decoder_logits_to_img(torch.zeros(2)), torch.full((2,), 0.5))
+
+
+def test_cli_flag_set_is_the_reference_one():
+    from vqvae_amd.scripts.build_codebook import make_parser
+    args = make_parser().parse_args([
+        "--latents_path", "z.pt", "--out_dir", "o", "--vae_ckpt_path", "b.pt", "--in_channels", "1",
+        "--output_image_size", "28", "--latent_dim", "16", "--enc_channels", "64", "128", "256",
+        "--dec_channels", "256", "128", "64", "--recon_loss", "mse", "--norm_type", "batch"])
+    assert (args.k, args.sym, args.K, args.init, args.seed, args.batch_size) == (20, "union", 512, "kpp", 42, 512)
+    assert args.mse_use_sigmoid is False and args.dec_channels == [256, 128, 64]
+    with pytest.raises(SystemExit):
+        make_parser().parse_args(["--latents_path", "z.pt"])

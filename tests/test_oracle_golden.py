@@ -1,0 +1,157 @@
+"""The oracle (oracle/, CPU restatement) against the golden vectors generated from the reference import
+(tests/golden/*.npz, oracle/gen_golden.py) and against the reference's own known-answer tests
+(reference tests/test_geo_shortest_paths.py:37-46,56-71,82-90).  Runs on CPU."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from conftest import clustered_latents, csr_from_golden, latents
+from oracle import kmedoids as ok
+from oracle import knn as okn
+from oracle import metric as om
+from oracle import pipeline as op
+from oracle import sssp as osp
+
+KNN_CASES = {"g16": (2048, 16, 0), "g32": (512, 32, 1), "g64": (300, 64, 2), "g8": (400, 8, 3)}
+
+
+def line_graph(N, w=1.0):
+    rows, cols, data = [], [], []
+    for i in range(N - 1):
+        rows += [i, i + 1]
+        cols += [i + 1, i]
+        data += [w, w]
+    return sparse.csr_matrix((data, (rows, cols)), shape=(N, N), dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", ["g32", "g64", "g8"])
+def test_knn_graph_structure_equals_reference(golden, name):
+    g = golden("knn")
+    N, d, seed = KNN_CASES[name]
+    z = latents(N, d, seed)
+    for k in (1, 5, 20):
+        for mode in ("connectivity", "distance"):
+            for sym in ("union", "mutual"):
+                tag = f"{name}/k{k}/{mode}/{sym}"
+                W, info = okn.build_knn_graph_auto(z, k=k, mode=mode, sym=sym)
+                W.sort_indices()
+                np.testing.assert_array_equal(W.indptr, g[f"{tag}/indptr"], err_msg=tag)
+                np.testing.assert_array_equal(W.indices, g[f"{tag}/indices"], err_msg=tag)
+                if mode == "distance":
+                    ref = g[f"{tag}/data"]
+                    assert np.max(np.abs(W.data.astype(np.float64) - ref) / np.spacing(ref)) <= 1.0
+        np.testing.assert_array_equal(info["indices"], g[f"{name}/k{k}/nbr_indices"])
+
+
+def test_knn_c1_graph_equals_reference(golden):
+    g = golden("knn")
+    W, _ = okn.build_knn_graph_auto(latents(2048, 16, 0), k=20, mode="connectivity", sym="union")
+    W.sort_indices()
+    np.testing.assert_array_equal(W.indptr, g["g16/k20/connectivity/union/indptr"])
+    np.testing.assert_array_equal(W.indices, g["g16/k20/connectivity/union/indices"])
+
+
+def test_knn_duplicates_differ_only_at_ties(golden):
+    g = golden("knn")
+    z = clustered_latents(256, 16, 4)
+    dup_nodes = {3, 5, 15, 16, 17, 128, 255}
+    W, info = okn.build_knn_graph_auto(z, k=5, mode="connectivity", sym="union")
+    Wr = csr_from_golden(g, "dup16/k5/connectivity/union", 256, with_data=False)
+    diff = abs(W - Wr).tocoo()
+    assert all((r in dup_nodes) or (c in dup_nodes) for r, c, v in zip(diff.row, diff.col, diff.data) if v != 0)
+
+
+def test_sssp_known_answers_from_reference_tests():
+    D = osp.dijkstra_multi_source(line_graph(5), [0, 2])
+    np.testing.assert_array_equal(D[0], np.array([0, 1, 2, 3, 4], np.float32))
+    np.testing.assert_array_equal(D[1], np.array([2, 1, 0, 1, 2], np.float32))
+    W = sparse.csr_matrix((np.array([1, 1, 10, 10], np.float32), ([0, 1, 1, 2], [1, 0, 2, 1])), shape=(3, 3))
+    assert osp.dijkstra_multi_source(W, [0])[0, 2] == 11.0
+    assert osp.dijkstra_multi_source(W, [0], unweighted=True)[0, 2] == 2.0
+    Wd = sparse.block_diag((line_graph(3), line_graph(4)), format="csr", dtype=np.float32)
+    D = osp.dijkstra_multi_source(Wd, [0, 3])
+    assert np.isinf(D[0, 3:]).all() and np.isinf(D[1, :3]).all()
+    D, P = osp.dijkstra_multi_source(line_graph(4), [0], return_predecessors=True)
+    assert D.dtype == np.float32 and P.dtype == np.int32 and list(P[0]) == [-9999, 0, 1, 2]
+    with pytest.raises(ValueError):
+        osp.dijkstra_multi_source(line_graph(3), [])
+    with pytest.raises(TypeError):
+        osp.ensure_valid_graph(np.zeros((2, 2)))
+
+
+def test_sssp_golden_bit_exact(golden):
+    gk, gs = golden("knn"), golden("sssp")
+    W = csr_from_golden(gk, "g16/k20/distance/union", 2048)
+    D, P = osp.dijkstra_multi_source(W, gs["g16/sources"], return_predecessors=True)
+    np.testing.assert_array_equal(D, gs["g16/D"])
+    np.testing.assert_array_equal(P, gs["g16/P"])
+    np.testing.assert_array_equal(osp.dijkstra_multi_source(W, gs["g16/sources"][:3], unweighted=True),
+                                  gs["g16/D_unweighted"])
+    Wt = sparse.triu(W).tocsr()
+    np.testing.assert_array_equal(osp.dijkstra_multi_source(Wt, [0, 5], directed=True), gs["g16/D_triu_directed"])
+    np.testing.assert_array_equal(osp.dijkstra_multi_source(Wt, [0, 5]), gs["g16/D_triu_undirected"])
+    Wm, _ = okn.build_knn_graph(latents(240, 12, 1), k=1, mode="distance", sym="mutual")
+    np.testing.assert_array_equal(osp.dijkstra_multi_source(Wm, [0, 10]), gs["disc/D"])
+    np.testing.assert_array_equal(okn.largest_connected_component(Wm), gs["disc/lcc"])
+
+
+def test_kmedoids_golden_and_single_pass(golden):
+    gk, gm = golden("knn"), golden("kmedoids")
+    Wd = csr_from_golden(gk, "g16/k20/distance/union", 2048)
+    Wm, _ = okn.build_knn_graph(latents(240, 12, 1), k=1, mode="distance", sym="mutual")
+    for gname, W in (("g16", Wd), ("disc", Wm)):
+        for K in (1, 8, 64):
+            for init in ("kpp", "random"):
+                tag = f"{gname}/K{K}/{init}/s42"
+                med, assign, qe = ok.fit_kmedoids_optimized(W, K=K, init=init, seed=42)
+                np.testing.assert_array_equal(med, gm[f"{tag}/medoids"])
+                np.testing.assert_array_equal(assign, gm[f"{tag}/assign"])
+                gq = float(gm[f"{tag}/qe"])
+                assert qe == gq or (np.isinf(qe) and np.isinf(gq))
+                if init == "kpp":
+                    m2, a2, q2 = ok.fit_kmedoids_single_pass(W, K=K, seed=42)
+                    np.testing.assert_array_equal(m2, med)
+                    np.testing.assert_array_equal(a2, assign)
+                    assert q2 == qe or (np.isinf(q2) and np.isinf(qe))
+    with pytest.raises(ValueError):
+        ok.fit_kmedoids_optimized(Wd, K=3, init="bogus")
+
+
+@pytest.mark.parametrize("name,cfg", [("fm_batch", (16, 1, 28, "batch", 10)), ("fm_none", (16, 1, 28, "none", 11)),
+                                      ("fm_group", (16, 1, 28, "group", 12)), ("cf_batch", (32, 3, 32, "batch", 13))])
+def test_metric_closed_form_vs_reference(golden, name, cfg):
+    d, cout, size, norm, seed = cfg
+    g = golden("metric")
+    sd = om.make_decoder_state(seed, d, cout, norm_type=norm)
+    r = np.random.RandomState(100 + seed)
+    zs = r.randn(2048, d).astype(np.float32)
+    ze = (zs + 0.3 * r.randn(2048, d)).astype(np.float32)
+    for training in (True, False):
+        L = om.edge_lengths(sd, norm, size, zs[:512], ze[:512], batch_size=512, training=training).numpy()
+        ref = g[f"{name}/train{int(training)}/bs512"][:512]
+        rel = np.abs(L - ref) / np.abs(ref)
+        assert np.mean(rel <= 1e-5) >= 0.998, rel.max()      # ReLU-boundary outliers allowed (SURVEY finding 9)
+
+
+def test_pipeline_c1_equals_reference_cli(golden):
+    g = golden("cli")
+    d, cout, size, seed, n_img = [int(x) for x in g["c1_fm/meta"]]
+    sd = om.make_decoder_state(seed, d, cout, norm_type="batch")
+    z4 = np.random.RandomState(seed).randn(n_img * 16, d).astype(np.float32).reshape(n_img, 4, 4, d)
+    z4 = np.ascontiguousarray(np.transpose(z4, (0, 3, 1, 2)))
+    # the JVP stage is the slow part on CPU: reuse the reference's graph weights and check what follows
+    W = sparse.csr_matrix((g["c1_fm/data"], g["c1_fm/indices"], g["c1_fm/indptr"]), shape=(2048, 2048))
+    med, assign, qe = ok.fit_kmedoids_optimized(W, K=64, init="kpp", seed=42)
+    np.testing.assert_array_equal(med.astype(np.int32), g["c1_fm/medoid_indices"])
+    np.testing.assert_array_equal(assign.astype(np.int32).reshape(n_img, 4, 4), g["c1_fm/codes"])
+    np.testing.assert_array_equal(op.flatten_latents(z4)[med], g["c1_fm/z_medoid"])
+    We, _ = okn.build_knn_graph_auto(op.flatten_latents(z4), k=20, mode="connectivity", sym="union")
+    We.sort_indices()
+    np.testing.assert_array_equal(We.indptr, g["c1_fm/indptr"])
+    np.testing.assert_array_equal(We.indices, g["c1_fm/indices"])
+    edges = op.upper_edges(We)
+    L = om.edge_lengths(sd, "batch", size, op.flatten_latents(z4)[edges[:1024, 0]], op.flatten_latents(z4)[edges[:1024, 1]],
+                        batch_size=512, training=True).numpy()
+    ref = np.asarray(W[edges[:1024, 0], edges[:1024, 1]]).ravel()
+    assert np.mean(np.abs(L - ref) / ref <= 1e-5) >= 0.998

@@ -3,6 +3,9 @@ entry point without the built library raises, and every call checks the returned
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must come first: libgeo_hip.so has to bind to the HIP runtime PyTorch-ROCm loads,
+#                              so that device pointers and streams are shared (two runtimes = "no device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgeo_hip.so")
 
@@ -24,6 +27,7 @@ _SIGNATURES = {
     "geo_last_error": (ctypes.c_char_p, []),
     "geo_sssp_workspace_bytes": (sz, [i32, i32]),
     "geo_sssp_multi": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, sz, c_p, c_p]),
+    "geo_sssp_last_profile": (ctypes.c_int, [c_p, c_p]),
     "geo_sssp_single_update": (ctypes.c_int, [c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i32, c_p, sz, c_p, c_p]),
     "geo_knn_workspace_bytes": (sz, [i64, i32]),
     "geo_knn_topk": (ctypes.c_int, [c_p, i64, i32, i32, i32, i64, i64, c_p, c_p, c_p, sz, c_p]),

@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256) void finish_single_kernel(const double *__rest
     }
 }
 
+// device time of the relaxation sweeps of the last geo_sssp_multi call (HIP events on its stream)
+double g_last_sweep_ms = 0.0;
+int32_t g_last_sweep_launches = 0;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+
 struct MultiWs {
     double *dist;
     int32_t *pred;
@@ -271,8 +276,14 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     int32_t sweeps = 0;
     bool done = false;
     const int64_t limit = (int64_t)n + 2;
+    if (!g_ev0) {
+        GEO_HIP_CHECK(hipEventCreate(&g_ev0));
+        GEO_HIP_CHECK(hipEventCreate(&g_ev1));
+    }
+    g_last_sweep_ms = 0.0;
     while (!done) {
         int last_cur = 0;
+        GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
         for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
             const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
             if (weights)
@@ -284,9 +295,13 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
             GEO_LAUNCH_CHECK();
             last_cur = cur;
         }
+        GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
         GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
                                      hipMemcpyDeviceToHost, stream));
         GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+        g_last_sweep_ms += ms;
         done = true;
         for (int32_t b = 0; b < nb; ++b) done = done && (hflags[b] == 0);
         if (!done && sweeps > limit) {
@@ -295,6 +310,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         }
     }
     if (sweeps_out) *sweeps_out = sweeps;
+    g_last_sweep_launches = sweeps;
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {
@@ -317,6 +333,12 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         GEO_LAUNCH_CHECK();
     }
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    return GEO_OK;
+}
+
+extern "C" int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches) {
+    if (sweep_ms) *sweep_ms = g_last_sweep_ms;
+    if (sweep_launches) *sweep_launches = g_last_sweep_launches;
     return GEO_OK;
 }
 
