@@ -324,7 +324,10 @@ __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t
 }
 
 // ---------------------------------------------------------------------------------- back
-// One workgroup = BACK_TS sample slots.  a2 / ta2 [BACK_TS][16 px][c2] in LDS (dynamic).
+// One workgroup = BACK_TS sample slots.  LDS (dynamic): a2 / ta2 [BACK_TS][16 px][c2] after norm2 + ReLU,
+// the packed ConvT3 taps W3p [16][co][c2], and the squared tangent outputs.  A work item is
+// (sample, output element, channel quarter): the 4 quarters of a dot product sit in adjacent lanes and are
+// summed with two shuffles, so all 256 threads are busy even for the 16-pixel FashionMNIST head.
 __global__ __launch_bounds__(256) void back_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
                                                   const NormConst *__restrict__ consts2, int consts_per_group,
                                                   int slots_per_group, int c2, int co_n, int s_out, int pad3,
@@ -332,43 +335,64 @@ __global__ __launch_bounds__(256) void back_kernel(const float *__restrict__ pre
                                                   float *__restrict__ norms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n2 = 16 * c2;
-    float *a2 = smem;                                   // [BACK_TS][n2]
-    float *ta2 = smem + (size_t)BACK_TS * n2;           // [BACK_TS][n2]
-    float *jt2 = ta2 + (size_t)BACK_TS * n2;            // [BACK_TS][p_out]
     const int p_out = co_n * s_out * s_out;
+    const int ldc = c2 + 4;                             // padded pixel row: neighbouring pixels / taps start on
+    const int lds_n2 = 16 * ldc;                        // different LDS banks (c2 is a multiple of the bank cycle)
+    float *a2 = smem;                                   // [BACK_TS][16][ldc]
+    float *ta2 = a2 + (size_t)BACK_TS * lds_n2;         // [BACK_TS][16][ldc]
+    float *w3 = ta2 + (size_t)BACK_TS * lds_n2;         // [16 taps * co_n][ldc]
+    float *jt2 = w3 + (size_t)16 * co_n * ldc;          // [BACK_TS][p_out]
     const size_t slot0 = (size_t)blockIdx.x * BACK_TS;
     const int group = (int)(slot0 / slots_per_group);
     const NormConst *kc = consts2 + (size_t)(consts_per_group ? group : 0) * c2;
-    for (int i = threadIdx.x; i < BACK_TS * n2; i += 256) {
-        const int c = i % c2;
-        float a, ta;
-        norm_relu(kc[c], pre2[slot0 * n2 + i], tpre2[slot0 * n2 + i], &a, &ta);
-        a2[i] = a;
-        ta2[i] = ta;
+    {
+        const float4 *xp4 = reinterpret_cast<const float4 *>(pre2 + slot0 * n2);
+        const float4 *xt4 = reinterpret_cast<const float4 *>(tpre2 + slot0 * n2);
+        const int c4n = c2 / 4;
+        for (int i = threadIdx.x; i < BACK_TS * n2 / 4; i += 256) {
+            const float4 x = xp4[i], t = xt4[i];
+            const int c = (i % c4n) * 4, row = i / c4n;              // row = s*16 + px
+            float4 a, ta;
+            norm_relu(kc[c], x.x, t.x, &a.x, &ta.x);
+            norm_relu(kc[c + 1], x.y, t.y, &a.y, &ta.y);
+            norm_relu(kc[c + 2], x.z, t.z, &a.z, &ta.z);
+            norm_relu(kc[c + 3], x.w, t.w, &a.w, &ta.w);
+            *reinterpret_cast<float4 *>(a2 + (size_t)row * ldc + c) = a;
+            *reinterpret_cast<float4 *>(ta2 + (size_t)row * ldc + c) = ta;
+        }
+        for (int i = threadIdx.x; i < 16 * co_n * c2; i += 256) w3[(size_t)(i / c2) * ldc + (i % c2)] = W3p[i];
     }
     __syncthreads();
-    for (int item = threadIdx.x; item < BACK_TS * p_out; item += 256) {
-        const int s = item / p_out, o = item % p_out;
+    const int qlen = c2 / 4;                             // c2 is a multiple of 16 (checked on the host)
+    for (int item = threadIdx.x; item < BACK_TS * p_out * 4; item += 256) {
+        const int q = item & 3, so = item >> 2;
+        const int s = so / p_out, o = so % p_out;
         const int co = o / (s_out * s_out), oy = (o / s_out) % s_out, ox = o % s_out;
-        float x = b3[co], t = 0.f;
+        float x = 0.f, t = 0.f;
         for (int iy = 0; iy < 4; ++iy) {
             const int ky = oy + pad3 - 2 * iy;
             if (ky < 0 || ky > 3) continue;
             for (int ix = 0; ix < 4; ++ix) {
                 const int kx = ox + pad3 - 2 * ix;
                 if (kx < 0 || kx > 3) continue;
-                const float *w = W3p + ((size_t)(ky * 4 + kx) * co_n + co) * c2;
-                const float *pa = a2 + (size_t)s * n2 + (iy * 4 + ix) * c2;
-                const float *pt = ta2 + (size_t)s * n2 + (iy * 4 + ix) * c2;
-                for (int ci = 0; ci < c2; ++ci) {
-                    x = fmaf(pa[ci], w[ci], x);
-                    t = fmaf(pt[ci], w[ci], t);
+                const float4 *w = reinterpret_cast<const float4 *>(w3 + ((size_t)(ky * 4 + kx) * co_n + co) * ldc + q * qlen);
+                const float4 *pa = reinterpret_cast<const float4 *>(a2 + ((size_t)s * 16 + iy * 4 + ix) * ldc + q * qlen);
+                const float4 *pt = reinterpret_cast<const float4 *>(ta2 + ((size_t)s * 16 + iy * 4 + ix) * ldc + q * qlen);
+                for (int c4 = 0; c4 < qlen / 4; ++c4) {
+                    const float4 wv = w[c4], av = pa[c4], tv = pt[c4];
+                    x = fmaf(av.x, wv.x, x); x = fmaf(av.y, wv.y, x); x = fmaf(av.z, wv.z, x); x = fmaf(av.w, wv.w, x);
+                    t = fmaf(tv.x, wv.x, t); t = fmaf(tv.y, wv.y, t); t = fmaf(tv.z, wv.z, t); t = fmaf(tv.w, wv.w, t);
                 }
             }
         }
-        const float sg = 1.0f / (1.0f + expf(-x));
-        const float j = t * sg * (1.0f - sg);
-        jt2[item] = j * j;
+        x += __shfl_xor(x, 1, 64); t += __shfl_xor(t, 1, 64);
+        x += __shfl_xor(x, 2, 64); t += __shfl_xor(t, 2, 64);
+        if (q == 0) {
+            x += b3[co];
+            const float sg = 1.0f / (1.0f + expf(-x));
+            const float j = t * sg * (1.0f - sg);
+            jt2[so] = j * j;
+        }
     }
     __syncthreads();
     // fixed-order fp64 sum per sample by one wave
@@ -474,7 +498,9 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     GEO_REQUIRE(s.d >= 1 && s.d <= 64, "geo_decoder_jvp: latent_dim %d not in [1,64]", s.d);
     GEO_REQUIRE(s.c1 == 128 || s.c1 == 64 || s.c1 == 32, "geo_decoder_jvp: dec_channels[1]=%d not in {32,64,128}", s.c1);
     GEO_REQUIRE(dc->norm == 0 || dc->norm == 1, "geo_decoder_jvp: norm_type 'group' is not implemented in the HIP path");
-    const size_t back_lds = ((size_t)2 * BACK_TS * s.n2 + (size_t)BACK_TS * s.p_out) * 4;
+    GEO_REQUIRE(s.c2 % 16 == 0, "geo_decoder_jvp: dec_channels[2]=%d must be a multiple of 16", s.c2);
+    const size_t back_lds = ((size_t)2 * BACK_TS * 16 * (s.c2 + 4) + (size_t)16 * s.co * (s.c2 + 4) +
+                             (size_t)BACK_TS * s.p_out) * 4;
     GEO_REQUIRE(back_lds <= 160 * 1024, "geo_decoder_jvp: decoder too wide for the back kernel (%zu B LDS)", back_lds);
     if (ws_bytes < pl.bytes) {
         geo::set_error("geo_decoder_jvp: workspace %zu < %zu", ws_bytes, pl.bytes);

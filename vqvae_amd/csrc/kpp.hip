@@ -35,56 +35,105 @@ constexpr int FINISH_GRID = 256;
 
 struct KppCtl {
     int32_t abort_iter, abort_reason;      // -1 / 0 while healthy; reason 1 solve, 2 margin, 3 degenerate
-    int32_t cur_src;
+    int32_t n_touched;                     // nodes whose distance was lowered by the current solve
     int32_t found, pick_idx, pick_ok;
+    int32_t fcount[3];                     // frontier sizes, ring over sweeps
     float total;
+    float maxf;                            // max finite d_min (-1: none), basis of the pruning margin
     double s_last;
 };
 
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
 __device__ __forceinline__ float inf32() { return __int_as_float(0x7f800000); }
 
-__global__ __launch_bounds__(256) void kpp_init_kernel(KppCtl *ctl, const int32_t *__restrict__ centers, int32_t pos,
-                                                      double *__restrict__ d, int32_t n, int32_t *flags) {
-    if (ctl->abort_iter >= 0) return;
-    const int32_t source = centers[pos];
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        d[i] = (i == source) ? 0.0 : inf64();
-    if (blockIdx.x == 0 && threadIdx.x < 3) flags[threadIdx.x] = 0;
+// ---- pruned frontier solve -------------------------------------------------------------------
+// Only nodes the new centre can still improve matter for d_min / argmin: a node whose tentative
+// distance from the new centre exceeds its current d_min by more than tau = 1e-6 * max_finite(d_min)
+// is not expanded.  Every path through such a node reaches its successors later than their current
+// d_min (triangle inequality through that node's own centre; tau is ~8x the worst f32/fp64
+// rounding of the quantities involved, all of which are < 2*max_finite), so no update is lost, and
+// nodes that ARE updated have an all-unpruned optimal path, hence their exact fixed-point distance.
+// Work per solve drops from O(nnz) per sweep to the size of the new centre's cell.
+__global__ void kpp_begin_kernel(KppCtl *ctl, const int32_t *__restrict__ centers, int32_t pos, double *d,
+                                 int32_t *seen, int32_t *touched, int32_t *front0, int32_t stamp_solve) {
+    if (ctl->abort_iter >= 0 || threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t src = centers[pos];
+    d[src] = 0.0;
+    seen[src] = stamp_solve;
+    touched[0] = src;
+    front0[0] = src;
+    ctl->n_touched = 1;
+    ctl->fcount[0] = 1;
+    ctl->fcount[1] = 0;
+    ctl->fcount[2] = 0;
 }
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void kpp_sweep_kernel(const KppCtl *ctl, const int32_t *__restrict__ indptr,
-                                                       const int32_t *__restrict__ indices,
-                                                       const float *__restrict__ weights, int32_t n, double *d,
-                                                       int32_t *flags, int prev, int cur, int next, int first) {
+__global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ weights, double *d,
+                                                      const float *__restrict__ dmin, int32_t *seen, int32_t *mark,
+                                                      int32_t *touched, const int32_t *__restrict__ fin,
+                                                      int32_t *__restrict__ fout, int cur, int next, int clear,
+                                                      int32_t stamp_solve, int32_t stamp_sweep) {
     if (ctl->abort_iter >= 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[next] = 0;
-    if (!first && flags[prev] == 0) return;
-    if (geo::sweep_single_body<WEIGHTED>(indptr, indices, weights, n, d)) flags[cur] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
+    const int32_t cnt = ctl->fcount[cur];
+    if (cnt == 0) return;
+    const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
+    const int sub = threadIdx.x & 15;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ngrp = (gridDim.x * blockDim.x) >> 4;
+    unsigned long long *dbits = reinterpret_cast<unsigned long long *>(d);
+    for (int32_t i = grp; i < cnt; i += ngrp) {
+        const int32_t u = fin[i];
+        const double du = d[u];
+        if (du > (double)dmin[u] + tau) continue;          // pruned: cannot improve anything behind it
+        for (int32_t e = indptr[u] + sub; e < indptr[u + 1]; e += 16) {
+            const int32_t v = indices[e];
+            const double cand = du + (WEIGHTED ? (double)weights[e] : 1.0);
+            const unsigned long long cb = (unsigned long long)__double_as_longlong(cand);
+            if (cb >= dbits[v]) continue;                   // cheap pre-test (monotone: values only decrease)
+            const unsigned long long old = atomicMin(&dbits[v], cb);
+            if (cb < old) {
+                if (atomicMax(&seen[v], stamp_solve) < stamp_solve) touched[atomicAdd(&ctl->n_touched, 1)] = v;
+                if (cand <= (double)dmin[v] + tau && atomicMax(&mark[v], stamp_sweep) < stamp_sweep)
+                    fout[atomicAdd(&ctl->fcount[next], 1)] = v;
+            }
+        }
+    }
 }
 
-__global__ void kpp_verdict_kernel(KppCtl *ctl, const int32_t *flags, int last_cur, int32_t iter) {
+// d_min / argmin update over the touched nodes (kmeans_optimized.py:44 + the single-pass assignment);
+// resets their distances for the next solve.  Aborts (nothing applied) when the frontier is not empty.
+__global__ __launch_bounds__(256) void kpp_finish_kernel(KppCtl *ctl, double *d, float *__restrict__ dmin,
+                                                        int32_t *__restrict__ argmin, const int32_t *__restrict__ touched,
+                                                        int last_next, int32_t pos) {
     if (ctl->abort_iter >= 0) return;
-    if (flags[last_cur] != 0) { ctl->abort_iter = iter; ctl->abort_reason = 1; }
+    if (ctl->fcount[last_next] != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
+        return;                                             // every block sees the same final count
+    }
+    const int32_t nt = ctl->n_touched;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += gridDim.x * blockDim.x) {
+        const int32_t v = touched[i];
+        const float x = (float)d[v];
+        if (x < dmin[v]) {
+            dmin[v] = x;
+            argmin[v] = pos;
+        }
+        d[v] = inf64();
+    }
 }
 
-// d_min / argmin update (kmeans_optimized.py:44 + the single-pass assignment) and per-block maxima
-// of the finite d_min for the inf -> 2*max_finite rule (:47-50).
-__global__ __launch_bounds__(256) void kpp_finish_kernel(const KppCtl *ctl, const double *__restrict__ d, int32_t n,
-                                                        float *__restrict__ dmin, int32_t *__restrict__ argmin,
-                                                        int32_t pos, float *__restrict__ part_max) {
+// per-block maxima of the finite d_min for the inf -> 2*max_finite rule (:47-50) and the pruning margin
+__global__ __launch_bounds__(256) void kpp_max_kernel(const KppCtl *ctl, const float *__restrict__ dmin, int32_t n,
+                                                     float *__restrict__ part_max) {
     if (ctl->abort_iter >= 0) return;
     __shared__ float smax[4];
     float m = -1.0f;                                   // distances are >= 0: -1 means "no finite value seen"
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float x = (float)d[i];
-        float cur = dmin[i];
-        if (x < cur) {
-            cur = x;
-            dmin[i] = x;
-            argmin[i] = pos;
-        }
+        const float cur = dmin[i];
         if (cur < inf32()) m = fmaxf(m, cur);
     }
 #pragma unroll
@@ -94,7 +143,20 @@ __global__ __launch_bounds__(256) void kpp_finish_kernel(const KppCtl *ctl, cons
     if (threadIdx.x == 0) part_max[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
 }
 
-__global__ __launch_bounds__(256) void kpp_probs_kernel(const KppCtl *ctl, const float *__restrict__ dmin,
+__global__ void kpp_maxfin_kernel(KppCtl *ctl, const float *__restrict__ part_max, int n_part) {
+    if (ctl->abort_iter >= 0) return;
+    float m = -1.0f;
+    for (int i = threadIdx.x; i < n_part; i += 64) m = fmaxf(m, part_max[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (threadIdx.x == 0) ctl->maxf = m;
+}
+
+__global__ __launch_bounds__(256) void kpp_fill_inf_kernel(double *__restrict__ d, int32_t n) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = inf64();
+}
+
+__global__ __launch_bounds__(256) void kpp_probs_kernel(KppCtl *ctl, const float *__restrict__ dmin,
                                                        const uint8_t *__restrict__ is_center, int32_t n,
                                                        const float *__restrict__ part_max, int n_part,
                                                        float *__restrict__ probs) {
@@ -109,6 +171,7 @@ __global__ __launch_bounds__(256) void kpp_probs_kernel(const KppCtl *ctl, const
     }
     __syncthreads();
     const float maxf = smax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->maxf = maxf;      // pruning margin of the next solve
     const bool any_finite = maxf >= 0.0f;
     const float sub = maxf * 2.0f;
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -118,37 +181,49 @@ __global__ __launch_bounds__(256) void kpp_probs_kernel(const KppCtl *ctl, const
     }
 }
 
-// numpy float32 add.reduce of probs (see file header).  One block.
-__global__ __launch_bounds__(1024) void kpp_total_kernel(KppCtl *ctl, const float *__restrict__ a,
-                                                        const int32_t *__restrict__ leaf_start,
-                                                        const int32_t *__restrict__ leaf_len, int n_leaves,
-                                                        const int32_t *__restrict__ node_l,
-                                                        const int32_t *__restrict__ node_r,
-                                                        const int32_t *__restrict__ level_off, int n_levels,
-                                                        const int32_t *__restrict__ chunk_root, int n_chunks,
-                                                        float *__restrict__ val, int32_t iter) {
+// numpy float32 add.reduce of probs (see file header), stage 1: leaf sums.  8 lanes own the 8 strided
+// accumulators r[0..7] of one <=128-element leaf; they are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
+__global__ __launch_bounds__(256) void kpp_leaf_kernel(const KppCtl *ctl, const float *__restrict__ a,
+                                                      const int32_t *__restrict__ leaf_start,
+                                                      const int32_t *__restrict__ leaf_len, int n_leaves,
+                                                      float *__restrict__ val) {
     if (ctl->abort_iter >= 0) return;
-    for (int leaf = threadIdx.x; leaf < n_leaves; leaf += blockDim.x) {
-        const float *x = a + leaf_start[leaf];
-        const int len = leaf_len[leaf];
-        float res;
-        if (len < 8) {
-            res = 0.0f;
-            for (int i = 0; i < len; ++i) res += x[i];
-        } else {
-            float r0 = x[0], r1 = x[1], r2 = x[2], r3 = x[3], r4 = x[4], r5 = x[5], r6 = x[6], r7 = x[7];
-            int i = 8;
-            const int m = len - (len % 8);
-            for (; i < m; i += 8) {
-                r0 += x[i]; r1 += x[i + 1]; r2 += x[i + 2]; r3 += x[i + 3];
-                r4 += x[i + 4]; r5 += x[i + 5]; r6 += x[i + 6]; r7 += x[i + 7];
-            }
-            res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-            for (; i < len; ++i) res += x[i];
-        }
-        val[leaf] = res;
+    const int j = threadIdx.x & 7;
+    const int leaf = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool live = leaf < n_leaves;
+    const float *x = a + (live ? leaf_start[leaf] : 0);
+    const int len = live ? leaf_len[leaf] : 0;
+    const int m = len - (len % 8);
+    float r = 0.0f;
+    if (len >= 8) {
+        r = x[j];
+        for (int i = 8; i < m; i += 8) r += x[i + j];
     }
-    __syncthreads();
+    // lanes (0,1) (2,3) (4,5) (6,7) -> lanes 0,2,4,6 ; then (0,2) (4,6) -> 0,4 ; then (0,4) -> 0
+    float o = __shfl_down(r, 1, 8);
+    if ((j & 1) == 0) r += o;
+    o = __shfl_down(r, 2, 8);
+    if ((j & 3) == 0) r += o;
+    o = __shfl_down(r, 4, 8);
+    if (j == 0) {
+        r += o;
+        if (len < 8) {
+            r = 0.0f;
+            for (int i = 0; i < len; ++i) r += x[i];
+        } else {
+            for (int i = m; i < len; ++i) r += x[i];
+        }
+        if (live) val[leaf] = r;
+    }
+}
+
+// stage 2 (one block): the halving tree above the leaves, then the chunk roots accumulated in order.
+__global__ __launch_bounds__(1024) void kpp_tree_kernel(KppCtl *ctl, int n_leaves, const int32_t *__restrict__ node_l,
+                                                       const int32_t *__restrict__ node_r,
+                                                       const int32_t *__restrict__ level_off, int n_levels,
+                                                       const int32_t *__restrict__ chunk_root, int n_chunks,
+                                                       float *__restrict__ val, int32_t iter) {
+    if (ctl->abort_iter >= 0) return;
     for (int lv = 0; lv < n_levels; ++lv) {
         for (int j = level_off[lv] + threadIdx.x; j < level_off[lv + 1]; j += blockDim.x)
             val[n_leaves + j] = val[node_l[j]] + val[node_r[j]];
@@ -201,30 +276,28 @@ __global__ __launch_bounds__(SCAN_T) void kpp_scan_tiles_kernel(const KppCtl *ct
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
 }
 
-__global__ void kpp_scan_offsets_kernel(KppCtl *ctl, const double *__restrict__ tile_sum, int n_tiles,
-                                        double *__restrict__ tile_off) {
-    if (ctl->abort_iter >= 0) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double run = 0.0;
-        for (int t = 0; t < n_tiles; ++t) { tile_off[t] = run; run += tile_sum[t]; }
-        ctl->s_last = run;
-    }
-}
-
-// idx = searchsorted(cdf / cdf[-1], u, side='right') with a safety margin around u
+// idx = searchsorted(cdf / cdf[-1], u, side='right') with a safety margin around u.  Every block first
+// rebuilds the exclusive tile offsets (sequential order, so all blocks agree bit for bit) in LDS.
 __global__ __launch_bounds__(256) void kpp_pick_kernel(KppCtl *ctl, const double *__restrict__ cdf,
-                                                      const double *__restrict__ tile_off, int32_t n, double u,
-                                                      double tol) {
+                                                      const double *__restrict__ tile_sum, int n_tiles, int32_t n,
+                                                      double u, double tol) {
     if (ctl->abort_iter >= 0) return;
-    const double s_last = ctl->s_last;
+    extern __shared__ __attribute__((aligned(16))) double toff[];          // [n_tiles + 1]
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < n_tiles; ++t) { toff[t] = run; run += tile_sum[t]; }
+        toff[n_tiles] = run;
+    }
+    __syncthreads();
+    const double s_last = toff[n_tiles];
     for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const double cj = (cdf[j] + tile_off[j / SCAN_TILE]) / s_last;
+        const double cj = (cdf[j] + toff[j / SCAN_TILE]) / s_last;
         if (j == 0 && cj > u) {                       // nothing <= u: index 0
             ctl->found = 1; ctl->pick_idx = 0; ctl->pick_ok = (cj - u > tol) ? 1 : 0;
         }
         if (cj <= u) {
             const bool last = j == n - 1;
-            const double cn = last ? inf64() : (cdf[j + 1] + tile_off[(j + 1) / SCAN_TILE]) / s_last;
+            const double cn = last ? inf64() : (cdf[j + 1] + toff[(j + 1) / SCAN_TILE]) / s_last;
             if (cn > u) {
                 ctl->found = 1; ctl->pick_idx = j + 1;
                 ctl->pick_ok = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
@@ -274,7 +347,7 @@ struct DevPlan {
 struct KppWs {
     KppCtl *ctl;
     double *d, *cdf, *tile_sum, *tile_off;
-    int32_t *flags;
+    int32_t *seen, *mark, *touched, *front[2];
     float *probs, *part_max;
     DevPlan plan;
     int32_t *plan_blob;
@@ -294,7 +367,11 @@ bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
     o->tile_sum = ar.take<double>(tiles + 1);
     o->tile_off = ar.take<double>(tiles + 1);
-    o->flags = ar.take<int32_t>(16);
+    o->seen = ar.take<int32_t>((size_t)n);
+    o->mark = ar.take<int32_t>((size_t)n);
+    o->touched = ar.take<int32_t>((size_t)n);
+    o->front[0] = ar.take<int32_t>((size_t)n);
+    o->front[1] = ar.take<int32_t>((size_t)n);
     o->probs = ar.take<float>((size_t)n);
     o->part_max = ar.take<float>(FINISH_GRID);
     o->plan_ints = plan_ints_bound(n);
@@ -309,7 +386,7 @@ extern "C" size_t geo_kpp_workspace_bytes(int32_t n) {
     if (n <= 0) return 4096;
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
     return geo::align_up(4 * sizeof(KppCtl)) + 2 * geo::align_up((size_t)n * 8) + 2 * geo::align_up((tiles + 1) * 8) +
-           geo::align_up(64) + geo::align_up((size_t)n * 4) + geo::align_up(FINISH_GRID * 4) +
+           6 * geo::align_up((size_t)n * 4) + geo::align_up(FINISH_GRID * 4) +
            2 * geo::align_up(plan_ints_bound(n) * 4) + 4096;
 }
 
@@ -320,8 +397,9 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GEO_REQUIRE(indptr && indices && centers && is_center && dmin && argmin && ws && status_out,
                 "geo_kpp_chain: null pointer");
+    GEO_REQUIRE((size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8 <= 64 * 1024, "geo_kpp_chain: n too large for the pick kernel");
     GEO_REQUIRE(n > 0 && 0 <= it0 && it0 <= it1 && it1 <= n_centers_total, "geo_kpp_chain: bad iteration range");
-    GEO_REQUIRE(sweeps_per_solve >= 2 && sweeps_per_solve <= 4096, "geo_kpp_chain: sweeps_per_solve out of range");
+    GEO_REQUIRE(sweeps_per_solve >= 2 && sweeps_per_solve < 4096 && it1 - it0 < 500000, "geo_kpp_chain: sweeps_per_solve out of range");
     GEO_REQUIRE(it1 - it0 <= 1 || u_host, "geo_kpp_chain: uniform deviates missing");
     KppWs w;
     if (!carve(ws, ws_bytes, n, &w)) {
@@ -367,34 +445,52 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     dp.node_r = dp.node_l + M; dp.level_off = dp.node_r + M; dp.chunk_root = dp.level_off + max_level + 1;
 
     KppCtl h0;
-    h0.abort_iter = -1; h0.abort_reason = 0; h0.cur_src = -1; h0.found = 0; h0.pick_idx = -1; h0.pick_ok = 0;
-    h0.total = 0.f; h0.s_last = 0.0;
+    h0.abort_iter = -1; h0.abort_reason = 0; h0.n_touched = 0; h0.found = 0; h0.pick_idx = -1; h0.pick_ok = 0;
+    h0.fcount[0] = h0.fcount[1] = h0.fcount[2] = 0;
+    h0.total = 0.f; h0.maxf = -1.f; h0.s_last = 0.0;
     GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, sizeof(KppCtl), hipMemcpyHostToDevice, s));
+    GEO_HIP_CHECK(hipMemsetAsync(w.seen, 0, (size_t)n * 4, s));
+    GEO_HIP_CHECK(hipMemsetAsync(w.mark, 0, (size_t)n * 4, s));
 
     const int g_lin = geo::grid_for(n, 256, 2048);
-    const int g_sweep = geo::grid_for(n, 16, 4096);
+    // frontier sweeps: the first solves cross the whole graph, later ones only the new centre's (pruned)
+    // cell, where a small grid keeps the launch itself cheap
+    const int g_push_big = geo::grid_for(n, 16, 1024), g_push_small = geo::grid_for(n, 16, 48);
     const int n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     const double tol = ((double)n + 16.0) * 4.440892098500626e-16;            // (n+16) * 2^-51
+    kpp_fill_inf_kernel<<<g_lin, 256, 0, s>>>(w.d, n);
+    kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max);
+    kpp_maxfin_kernel<<<1, 64, 0, s>>>(w.ctl, w.part_max, FINISH_GRID);
+    GEO_LAUNCH_CHECK();
     for (int32_t t = it0; t < it1; ++t) {
-        kpp_init_kernel<<<g_lin, 256, 0, s>>>(w.ctl, centers, t, w.d, n, w.flags);
-        int last_cur = 0;
+        const int32_t stamp_solve = (t - it0) + 1;
+        const int g_push = t < 16 ? g_push_big : g_push_small;
+        kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, t, w.d, w.seen, w.touched, w.front[0], stamp_solve);
+        int last_next = 0;
         for (int sw = 0; sw < sweeps_per_solve; ++sw) {
-            const int cur = sw % 3, prev = (sw + 2) % 3, next = (sw + 1) % 3;
+            const int cur = sw % 3, next = (sw + 1) % 3, clear = (sw + 2) % 3;
+            const int32_t stamp_sweep = stamp_solve * 4096 + sw;
             if (weights)
-                kpp_sweep_kernel<true><<<g_sweep, 256, 0, s>>>(w.ctl, indptr, indices, weights, n, w.d, w.flags, prev, cur, next, sw == 0);
+                kpp_push_kernel<true><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.seen, w.mark,
+                                                             w.touched, w.front[sw & 1], w.front[(sw + 1) & 1], cur, next,
+                                                             clear, stamp_solve, stamp_sweep);
             else
-                kpp_sweep_kernel<false><<<g_sweep, 256, 0, s>>>(w.ctl, indptr, indices, weights, n, w.d, w.flags, prev, cur, next, sw == 0);
-            last_cur = cur;
+                kpp_push_kernel<false><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.seen, w.mark,
+                                                              w.touched, w.front[sw & 1], w.front[(sw + 1) & 1], cur, next,
+                                                              clear, stamp_solve, stamp_sweep);
+            last_next = next;
         }
-        kpp_verdict_kernel<<<1, 1, 0, s>>>(w.ctl, w.flags, last_cur, t);
-        kpp_finish_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, w.d, n, dmin, argmin, t, w.part_max);
+        kpp_finish_kernel<<<geo::grid_for(n, 256, 256), 256, 0, s>>>(w.ctl, w.d, dmin, argmin, w.touched, last_next, t);
         if (t + 1 < n_centers_total) {
+            kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max);
             kpp_probs_kernel<<<g_lin, 256, 0, s>>>(w.ctl, dmin, is_center, n, w.part_max, FINISH_GRID, w.probs);
-            kpp_total_kernel<<<1, 1024, 0, s>>>(w.ctl, w.probs, dp.leaf_start, dp.leaf_len, dp.n_leaves, dp.node_l, dp.node_r,
-                                                dp.level_off, dp.n_levels, dp.chunk_root, dp.n_chunks, dp.val, t);
+            kpp_leaf_kernel<<<(dp.n_leaves * 8 + 255) / 256, 256, 0, s>>>(w.ctl, w.probs, dp.leaf_start, dp.leaf_len,
+                                                                          dp.n_leaves, dp.val);
+            kpp_tree_kernel<<<1, 1024, 0, s>>>(w.ctl, dp.n_leaves, dp.node_l, dp.node_r, dp.level_off, dp.n_levels,
+                                               dp.chunk_root, dp.n_chunks, dp.val, t);
             kpp_scan_tiles_kernel<<<n_tiles, SCAN_T, 0, s>>>(w.ctl, w.probs, n, w.cdf, w.tile_sum);
-            kpp_scan_offsets_kernel<<<1, 64, 0, s>>>(w.ctl, w.tile_sum, n_tiles, w.tile_off);
-            kpp_pick_kernel<<<g_lin, 256, 0, s>>>(w.ctl, w.cdf, w.tile_off, n, u_host[t], tol);
+            kpp_pick_kernel<<<g_lin, 256, (size_t)(n_tiles + 1) * sizeof(double), s>>>(w.ctl, w.cdf, w.tile_sum, n_tiles,
+                                                                                       n, u_host[t], tol);
             kpp_commit_kernel<<<1, 64, 0, s>>>(w.ctl, centers, is_center, t + 1, t);
         }
         GEO_LAUNCH_CHECK();

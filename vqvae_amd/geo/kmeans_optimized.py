@@ -133,18 +133,24 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
     it, it1 = 0, (K if absorb_last else K - 1)
     n_valid = K
-    sweeps = 12
+    # frontier sweeps enqueued per solve: the first solves cross the whole graph, later ones only the new
+    # centre's cell (pruned); a solve that needs more aborts harmlessly and is redone host-driven
+    sweeps, warm = 10, 16
     status = np.zeros(2, dtype=np.int32)
     while it < it1:
+        seg_end = min(it1, warm) if it < warm else it1
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
-                                         ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, it1, K,
-                                         sweeps, ptr(ws), ws.numel(), status.ctypes.data, stream_ptr()),
+                                         ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
+                                         K, 2 * sweeps if it < warm else sweeps, ptr(ws), ws.numel(),
+                                         status.ctypes.data, stream_ptr()),
                        "geo_kpp_chain")
-        chain.solves += it1 - it
         t, reason = int(status[0]), int(status[1])
         if t < 0:
-            break
+            chain.solves += seg_end - it
+            it = seg_end
+            continue
+        chain.solves += t - it + 1
         centers_h = centers_d[: t + 1].cpu().numpy().astype(int).tolist()
         if reason == 1:                                  # this solve needs more sweeps: host-driven solve
             sweeps = min(2 * sweeps, 4096)
