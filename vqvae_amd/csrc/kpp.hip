@@ -81,15 +81,17 @@ __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_
     const int32_t cnt = ctl->fcount[cur];
     if (cnt == 0) return;
     const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
-    const int sub = threadIdx.x & 15;
-    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int ngrp = (gridDim.x * blockDim.x) >> 4;
+    const int sub = threadIdx.x & 31;                       // 32 lanes share one frontier node (mean degree ~31)
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int ngrp = (gridDim.x * blockDim.x) >> 5;
     unsigned long long *dbits = reinterpret_cast<unsigned long long *>(d);
     for (int32_t i = grp; i < cnt; i += ngrp) {
         const int32_t u = fin[i];
         const double du = d[u];
-        if (du > (double)dmin[u] + tau) continue;          // pruned: cannot improve anything behind it
-        for (int32_t e = indptr[u] + sub; e < indptr[u + 1]; e += 16) {
+        const float dmu = dmin[u];
+        const int32_t e0 = indptr[u], e1 = indptr[u + 1];
+        if (du > (double)dmu + tau) continue;               // pruned: cannot improve anything behind it
+        for (int32_t e = e0 + sub; e < e1; e += 32) {
             const int32_t v = indices[e];
             const double cand = du + (WEIGHTED ? (double)weights[e] : 1.0);
             const unsigned long long cb = (unsigned long long)__double_as_longlong(cand);
@@ -455,7 +457,7 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     const int g_lin = geo::grid_for(n, 256, 2048);
     // frontier sweeps: the first solves cross the whole graph, later ones only the new centre's (pruned)
     // cell, where a small grid keeps the launch itself cheap
-    const int g_push_big = geo::grid_for(n, 16, 1024), g_push_small = geo::grid_for(n, 16, 48);
+    const int g_push_big = geo::grid_for(n, 32, 2048), g_push_small = geo::grid_for(n, 32, 256);
     const int n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     const double tol = ((double)n + 16.0) * 4.440892098500626e-16;            // (n+16) * 2^-51
     kpp_fill_inf_kernel<<<g_lin, 256, 0, s>>>(w.d, n);

@@ -77,13 +77,15 @@ def _drop_self(dist: torch.Tensor, idx: torch.Tensor):
     return dist_k.contiguous(), idx_k.contiguous()
 
 
-def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual"):
-    """Resident latents -> (DeviceCSR, distances f64 [N,k'], indices int32 [N,k']); k' = min(k, N-1) >= 1."""
+def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual", group=None):
+    """Resident latents -> (DeviceCSR, distances f64 [N,k'], indices int32 [N,k']); k' = min(k, N-1) >= 1.
+    With an initialised process group the query rows are sharded over the ranks (parallel.sharded_knn)."""
+    from ..parallel import sharded_knn
     if sym not in _SYM_MODE:
         raise ValueError(f"Invalid symmetry mode: {sym}")
     N = z.shape[0]
     k_eff = max(0, min(k, N - 1))
-    idx, d2 = knn_search_device(z, min(k_eff + 1, N))
+    idx, d2 = sharded_knn(z, min(k_eff + 1, N), knn_search_device, group)
     dist, idx = _drop_self(torch.sqrt(d2), idx)
     weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
     return symmetrize_device(idx, weights, sym), dist, idx

@@ -1,0 +1,121 @@
+"""Single-node multi-GPU sharding of the geodesic-codebook path: one process per
+GPU, `torch.distributed` collectives (backend "nccl" = RCCL over xGMI on the MI355X node, "gloo" in the
+CPU tests).  The reference has no distributed code; this layer is new.
+
+What shards and what is exchanged
+  kNN             query rows are block-sharded, the corpus is replicated (all-gather of the latent row
+                  shards, N*d*4 bytes) -> all-gather of the neighbour lists (N*(k+1)*12 bytes).
+  edge lengths    sharded by CHUNK index (a chunk of `batch_size` consecutive edges is one BatchNorm batch,
+                  so train-mode statistics do not change) -> all-gather of the lengths (E*4 bytes).
+  K-source solve  sources are block-sharded -> every rank reduces its sources to (dmin, argmin) per node ->
+                  all-gather (world*N*8 bytes) and a (min, lowest source index) merge: the first-index tie
+                  rule of D.argmin(axis=0) (kmeans_optimized.py:100) is not an all-reduce(min).
+  k-means++ chain inherently serial (each draw depends on all previous solves): replicated on every rank;
+                  it is deterministic, so all ranks hold the same centres without communication.
+
+The functions take the local compute as a callable, so the distributed logic is the same code on the GPU
+(HIP kernels) and in the gloo tests (which plug in the CPU oracle as the compute).
+"""
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def block_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced partition of range(n): the first n % world ranks get one extra item."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """Concatenate per-rank row blocks of known sizes `counts` (rows may differ by rank)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return local
+    width = max(counts)
+    pad_shape = (width,) + tuple(local.shape[1:])
+    padded = torch.zeros(pad_shape, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world,) + pad_shape, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=group)
+    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+def gather_latents(z_shard: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Row shards of the latent set -> the full corpus on every rank."""
+    _, world = world_info(group)
+    counts = [block_range(n_total, r, world)[1] - block_range(n_total, r, world)[0] for r in range(world)]
+    return all_gather_rows(z_shard.contiguous(), counts, group)
+
+
+def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=None):
+    """search_fn(z, n_neighbors, row0, row1) -> (idx [rows, n_neighbors], d2 [rows, n_neighbors]).
+    Returns the full (idx, d2) on every rank."""
+    rank, world = world_info(group)
+    n = z.shape[0]
+    r0, r1 = block_range(n, rank, world)
+    idx, d2 = search_fn(z, n_neighbors, r0, r1)
+    if world == 1:
+        return idx, d2
+    counts = [block_range(n, r, world)[1] - block_range(n, r, world)[0] for r in range(world)]
+    return all_gather_rows(idx, counts, group), all_gather_rows(d2, counts, group)
+
+
+def chunk_range(n_edges: int, batch_size: int, rank: int, world: int) -> Tuple[int, int]:
+    """Edge range [e0, e1) of this rank: whole chunks of `batch_size` edges, block-partitioned."""
+    n_chunks = (n_edges + batch_size - 1) // batch_size
+    c0, c1 = block_range(n_chunks, rank, world)
+    return min(c0 * batch_size, n_edges), min(c1 * batch_size, n_edges)
+
+
+def sharded_edge_lengths(n_edges: int, batch_size: int, length_fn: Callable, group=None) -> torch.Tensor:
+    """length_fn(e0, e1) -> f32 [e1 - e0] for edges [e0, e1) (e0 is a multiple of batch_size).
+    Returns all n_edges lengths on every rank."""
+    rank, world = world_info(group)
+    e0, e1 = chunk_range(n_edges, batch_size, rank, world)
+    local = length_fn(e0, e1)
+    if world == 1:
+        return local
+    counts = []
+    for r in range(world):
+        a, b = chunk_range(n_edges, batch_size, r, world)
+        counts.append(b - a)
+    return all_gather_rows(local, counts, group)
+
+
+def merge_min_argmin(dmin: torch.Tensor, arg: torch.Tensor, offsets: List[int], group=None):
+    """Per-rank (column minimum, first local row attaining it) over disjoint source blocks -> the global
+    (minimum, first row) with numpy's argmin tie rule: lowest global row index among equal minima;
+    an all-inf column keeps row 0."""
+    rank, world = world_info(group)
+    if world == 1:
+        return dmin, arg
+    n = dmin.shape[0]
+    all_d = torch.empty((world, n), dtype=dmin.dtype, device=dmin.device)
+    all_a = torch.empty((world, n), dtype=arg.dtype, device=arg.device)
+    dist.all_gather_into_tensor(all_d.view(-1), dmin.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_a.view(-1), (arg + offsets[rank]).contiguous(), group=group)
+    best_d, best_a = all_d[0].clone(), all_a[0].clone()
+    for r in range(1, world):                      # ranks own increasing source blocks: strict < keeps the lowest index
+        better = all_d[r] < best_d
+        best_d = torch.where(better, all_d[r], best_d)
+        best_a = torch.where(better, all_a[r], best_a)
+    return best_d, best_a
+
+
+def sharded_assign(n_sources: int, solve_fn: Callable, group=None):
+    """solve_fn(s0, s1) -> (dmin f32 [n], argmin i32 [n] local to [s0, s1)) for the source block [s0, s1)
+    (an empty block must return (+inf, 0)).  Returns the merged (dmin, argmin) on every rank."""
+    rank, world = world_info(group)
+    s0, s1 = block_range(n_sources, rank, world)
+    dmin, arg = solve_fn(s0, s1)
+    offsets = [block_range(n_sources, r, world)[0] for r in range(world)]
+    return merge_min_argmin(dmin, arg, offsets, group)

@@ -25,14 +25,17 @@ from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
                                        upper_edges_device)
 from ..geo.riemannian_metric import edge_lengths_graph_device
+from ..parallel import sharded_edge_lengths
 from ..spatial_decoder import DecoderExport, load_decoder_from_checkpoint
 
 
 def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: str = "union", K: int = 512,
                           init: str = "kpp", seed: int = 42, batch_size: int = 512,
-                          timers: Optional[Dict[str, float]] = None) -> dict:
+                          timers: Optional[Dict[str, float]] = None, group=None) -> dict:
     """The hot path on resident data.  z_flat: f32 [n_nodes, d] on the GPU, rows in (n, h, w) order.
-    Returns device/host results; `timers` (if given) receives per-stage seconds (synchronised)."""
+    Returns device/host results; `timers` (if given) receives per-stage seconds (synchronised).
+    Under an initialised torch.distributed group the kNN rows and the JVP chunks are sharded over the
+    ranks (vqvae_amd/parallel.py); every rank ends with the full result."""
     dev = z_flat.device
 
     def tick(name, t0):
@@ -42,13 +45,16 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
         return time.perf_counter()
 
     t0 = time.perf_counter()
-    G, _, _ = knn_graph_device(z_flat, k, mode="connectivity", sym=sym)
+    G, _, _ = knn_graph_device(z_flat, k, mode="connectivity", sym=sym, group=group)
     src, dst, entry_edge = upper_edges_device(G)
     t0 = tick("knn", t0)
 
     print(f"Re-weighting {src.numel()} edges using Riemannian metric...")
     export = DecoderExport(decoder, dev)
-    lengths = edge_lengths_graph_device(export, z_flat, src, dst, batch_size)
+    # whole chunks of `batch_size` edges per rank: every BatchNorm batch stays intact
+    lengths = sharded_edge_lengths(
+        int(src.numel()), batch_size,
+        lambda e0, e1: edge_lengths_graph_device(export, z_flat, src[e0:e1], dst[e0:e1], batch_size), group)
     t0 = tick("jvp", t0)
 
     W_geo = reweight_device(G, entry_edge, lengths)
