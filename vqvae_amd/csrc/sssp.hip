@@ -25,103 +25,150 @@
 
 namespace {
 
-constexpr int SB = 64;            // sources per batch = lanes per wave
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int SWEEP_GROUP = 4;    // sweeps enqueued between host convergence checks
 
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
 
+// lane J of every 16-lane row, broadcast to the whole row (DPP row_newbcast)
+template <int J>
+__device__ __forceinline__ int row_bcast(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xf, 0xf, false);
+}
+
+// One step of the 16-source relaxation: edge J of the 16 edges held one per lane in (idx, wbits).
+template <int J>
+__device__ __forceinline__ void relax_edge16(const double *__restrict__ D, int s, int idx, int wbits, int32_t cnt,
+                                             double &best) {
+    const int32_t u = row_bcast<J>(idx);
+    const float w = __int_as_float(row_bcast<J>(wbits));
+    if (J < cnt) best = fmin(best, D[(size_t)u * 16 + s] + (double)w);
+}
+
 // ------------------------------------------------------------------------------------ multi-source
+// dist[batch][node][sb]: `sb` sources per batch are the fast axis (sb in {64, 16}).
 __global__ __launch_bounds__(256) void init_multi_kernel(double *__restrict__ dist, const int32_t *__restrict__ src,
-                                                        int32_t n, int32_t nb) {
-    const int64_t total = (int64_t)nb * n * SB;
+                                                        int32_t n, int32_t nb, int32_t sb) {
+    const int64_t total = (int64_t)nb * n * sb;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int s = (int)(i & (SB - 1));
-        const int64_t r = i >> 6;
+        const int s = (int)(i % sb);
+        const int64_t r = i / sb;
         const int32_t v = (int32_t)(r % n);
         const int32_t b = (int32_t)(r / n);
-        dist[i] = (src[b * SB + s] == v) ? 0.0 : inf64();
+        dist[i] = (src[b * sb + s] == v) ? 0.0 : inf64();
     }
 }
 
 // One sweep over every (batch, node).  flags: ring of 3 slots x nb ints; this sweep reads slot
 // `prev`, sets slot `cur` where something changed and clears slot `next`.
-template <bool WEIGHTED>
+//
+// A wave relaxes 64/SBT nodes for the SBT sources of one batch (lane = node slot * SBT + source): each
+// neighbour row is one SBT*8-byte contiguous read.  Block order is batch-group major: blocks
+// [g*8*P, (g+1)*8*P) cover batches 8g .. 8g+7 with batch = 8g + (bid % 8).  Blocks are dealt round-robin
+// over the 8 XCDs and dispatched in order, so at any moment one XCD's L2 works on ONE batch whose
+// n*SBT*8 bytes of distances it can hold (4 MiB L2): every row is re-read ~deg times per sweep from L2
+// instead of the Infinity Cache (measured 17-19 TB/s vs 9 TB/s of gathered bytes).  Placement is a
+// speed matter only; results do not depend on it.
+template <int SBT, bool WEIGHTED>
 __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restrict__ indptr,
                                                          const int32_t *__restrict__ indices,
                                                          const float *__restrict__ weights, int32_t n, int32_t nb,
-                                                         double *dist, int32_t *flags, int prev, int cur, int next,
-                                                         int first) {
+                                                         int32_t blocks_per_batch, double *dist, int32_t *flags,
+                                                         int prev, int cur, int next, int first) {
+    constexpr int NPW = 64 / SBT;            // nodes per wave
+    constexpr int NPB = NPW * WAVES_PER_BLOCK;
     const int bid = blockIdx.x;
-    const int b = bid % nb;                 // batch <-> XCD affinity when nb is a multiple of 8
-    const int xb = bid / nb;
-    const int nxb = gridDim.x / nb;
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
-    if (xb >= nxb) return;                  // tail blocks when gridDim.x % nb != 0
+    const int group = bid / (8 * blocks_per_batch);
+    const int b = group * 8 + (bid & 7);
+    const int xb = (bid % (8 * blocks_per_batch)) >> 3;
+    if (b >= nb) return;
     if (!first && flags[prev * nb + b] == 0) return;   // this batch already reached its fixed point
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *D = dist + (size_t)b * n * SB;
+    const int wave = threadIdx.x >> 6;
+    const int slot = lane / SBT, s = lane % SBT;
+    double *D = dist + (size_t)b * n * SBT;
     bool any = false;
-    for (int32_t v = xb * WAVES_PER_BLOCK + wave; v < n; v += nxb * WAVES_PER_BLOCK) {
+    for (int32_t v0 = xb * NPB; v0 < n; v0 += blocks_per_batch * NPB) {
+        int32_t v = v0 + wave * NPW + slot;
+        if (SBT == 64) v = __builtin_amdgcn_readfirstlane(v);   // whole wave on one node: CSR row via scalar loads
+        if (v >= n) continue;
         const int32_t e0 = indptr[v], e1 = indptr[v + 1];
-        const double curv = D[(size_t)v * SB + lane];
+        const double curv = D[(size_t)v * SBT + s];
         double best = curv;
-        int32_t e = e0;
-        for (; e + 4 <= e1; e += 4) {
-            const int32_t u0 = indices[e], u1 = indices[e + 1], u2 = indices[e + 2], u3 = indices[e + 3];
-            const double d0 = D[(size_t)u0 * SB + lane], d1 = D[(size_t)u1 * SB + lane];
-            const double d2 = D[(size_t)u2 * SB + lane], d3 = D[(size_t)u3 * SB + lane];
-            const double w0 = WEIGHTED ? (double)weights[e] : 1.0, w1 = WEIGHTED ? (double)weights[e + 1] : 1.0;
-            const double w2 = WEIGHTED ? (double)weights[e + 2] : 1.0, w3 = WEIGHTED ? (double)weights[e + 3] : 1.0;
-            best = fmin(best, fmin(fmin(d0 + w0, d1 + w1), fmin(d2 + w2, d3 + w3)));
-        }
-        for (; e < e1; ++e) {
-            const double w = WEIGHTED ? (double)weights[e] : 1.0;
-            best = fmin(best, D[(size_t)indices[e] * SB + lane] + w);
+        if (SBT == 16) {
+            // the 16 lanes of a node slot fetch 16 consecutive CSR entries with ONE coalesced load each for
+            // columns and weights, then share them lane by lane through DPP: one gather per edge remains
+            for (int32_t e = e0; e < e1; e += 16) {
+                const int32_t cnt = e1 - e;                        // uniform inside the slot
+                const int idx = (s < cnt) ? indices[e + s] : 0;
+                const int wb = (s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0;
+                relax_edge16<0>(D, s, idx, wb, cnt, best); relax_edge16<1>(D, s, idx, wb, cnt, best);
+                relax_edge16<2>(D, s, idx, wb, cnt, best); relax_edge16<3>(D, s, idx, wb, cnt, best);
+                relax_edge16<4>(D, s, idx, wb, cnt, best); relax_edge16<5>(D, s, idx, wb, cnt, best);
+                relax_edge16<6>(D, s, idx, wb, cnt, best); relax_edge16<7>(D, s, idx, wb, cnt, best);
+                relax_edge16<8>(D, s, idx, wb, cnt, best); relax_edge16<9>(D, s, idx, wb, cnt, best);
+                relax_edge16<10>(D, s, idx, wb, cnt, best); relax_edge16<11>(D, s, idx, wb, cnt, best);
+                relax_edge16<12>(D, s, idx, wb, cnt, best); relax_edge16<13>(D, s, idx, wb, cnt, best);
+                relax_edge16<14>(D, s, idx, wb, cnt, best); relax_edge16<15>(D, s, idx, wb, cnt, best);
+            }
+        } else {
+            int32_t e = e0;
+            for (; e + 4 <= e1; e += 4) {
+                const int32_t u0 = indices[e], u1 = indices[e + 1], u2 = indices[e + 2], u3 = indices[e + 3];
+                const double d0 = D[(size_t)u0 * SBT + s], d1 = D[(size_t)u1 * SBT + s];
+                const double d2 = D[(size_t)u2 * SBT + s], d3 = D[(size_t)u3 * SBT + s];
+                const double w0 = WEIGHTED ? (double)weights[e] : 1.0, w1 = WEIGHTED ? (double)weights[e + 1] : 1.0;
+                const double w2 = WEIGHTED ? (double)weights[e + 2] : 1.0, w3 = WEIGHTED ? (double)weights[e + 3] : 1.0;
+                best = fmin(best, fmin(fmin(d0 + w0, d1 + w1), fmin(d2 + w2, d3 + w3)));
+            }
+            for (; e < e1; ++e) {
+                const double w = WEIGHTED ? (double)weights[e] : 1.0;
+                best = fmin(best, D[(size_t)indices[e] * SBT + s] + w);
+            }
         }
         if (best < curv) {
-            D[(size_t)v * SB + lane] = best;
+            D[(size_t)v * SBT + s] = best;
             any = true;
         }
     }
     if (__any(any) && lane == 0) flags[cur * nb + b] = 1;
 }
 
-// dist[b][v][s] (fp64) -> out[(b*64+s)][v] (f32), 64x64 tiles through LDS.
+// dist[b][v][s] -> out[(b*sb+s)][v], 64-node x sb-source tiles through LDS.
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void transpose_out_kernel(const TIn *__restrict__ in, TOut *__restrict__ out,
-                                                           int32_t n, int32_t n_sources) {
+                                                           int32_t n, int32_t n_sources, int32_t sb) {
     __shared__ TOut tile[64][65];
     const int b = blockIdx.y;
     const int32_t v0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int32_t v = v0 + i;
-        if (v < n) tile[i][tx] = (TOut)in[((size_t)b * n + v) * SB + tx];
+    for (int i = threadIdx.x; i < 64 * sb; i += 256) {
+        const int vi = i / sb, si = i % sb;
+        if (v0 + vi < n) tile[vi][si] = (TOut)in[((size_t)b * n + v0 + vi) * sb + si];
     }
     __syncthreads();
-    for (int s = ty; s < 64; s += 4) {
-        const int32_t row = b * SB + s;
-        const int32_t v = v0 + tx;
-        if (row < n_sources && v < n) out[(size_t)row * n + v] = tile[tx][s];
+    for (int i = threadIdx.x; i < 64 * sb; i += 256) {
+        const int si = i / 64, vi = i % 64;
+        const int32_t row = b * sb + si;
+        if (row < n_sources && v0 + vi < n) out[(size_t)row * n + v0 + vi] = tile[vi][si];
     }
 }
 
 // Column minimum of the f32 matrix and the first row attaining it (D.argmin(axis=0)).
-__global__ __launch_bounds__(256) void colmin_kernel(const double *__restrict__ dist, int32_t n, int32_t nb,
-                                                    int32_t n_sources, float *__restrict__ dmin,
+__global__ __launch_bounds__(256) void colmin_kernel(const double *__restrict__ dist, int32_t n, int32_t n_sources,
+                                                    int32_t sb, float *__restrict__ dmin,
                                                     int32_t *__restrict__ argmin) {
     const int lane = threadIdx.x & 63;
     const int32_t v = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (v >= n) return;
     float best = __int_as_float(0x7f800000);
     int32_t barg = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int32_t row = b * SB + lane;
-        float val = (row < n_sources) ? (float)dist[((size_t)b * n + v) * SB + lane] : __int_as_float(0x7f800000);
+    for (int32_t r0 = 0; r0 < n_sources; r0 += 64) {           // 64 consecutive source rows per step
+        const int32_t row = r0 + lane;
+        float val = __int_as_float(0x7f800000);
+        if (row < n_sources) val = (float)dist[((size_t)(row / sb) * n + v) * sb + (row % sb)];
         int32_t idx = row;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -138,31 +185,32 @@ __global__ __launch_bounds__(256) void colmin_kernel(const double *__restrict__ 
 }
 
 // Predecessor of every (source, node): the in-neighbour u with fl(d[u] + w) == d[v], smallest d[u]
-// first, then smallest index.  Written as pred[b][v][64] (i32) for the transposing store.
+// first, then smallest index.  Written as pred[b][v][sb] (i32) for the transposing store.
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void pred_multi_kernel(const int32_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const float *__restrict__ weights, int32_t n, int32_t nb,
-                                                        const double *__restrict__ dist, const int32_t *__restrict__ src,
-                                                        int32_t *__restrict__ pred) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double *D = dist + (size_t)b * n * SB;
-    const int32_t mysrc = src[b * SB + lane];
-    for (int32_t v = blockIdx.x * WAVES_PER_BLOCK + wave; v < n; v += gridDim.x * WAVES_PER_BLOCK) {
-        const double dv = D[(size_t)v * SB + lane];
+                                                        int32_t sb, const double *__restrict__ dist,
+                                                        const int32_t *__restrict__ src, int32_t *__restrict__ pred) {
+    const int64_t total = (int64_t)nb * n * sb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % sb);
+        const int64_t r = i / sb;
+        const int32_t v = (int32_t)(r % n);
+        const int32_t b = (int32_t)(r / n);
+        const double *D = dist + (size_t)b * n * sb;
+        const double dv = dist[i];
         int32_t p = -9999;
         double dp = inf64();
-        if (dv < inf64() && v != mysrc) {
+        if (dv < inf64() && v != src[b * sb + s]) {
             for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
                 const int32_t u = indices[e];
-                const double du = D[(size_t)u * SB + lane];
+                const double du = D[(size_t)u * sb + s];
                 const double w = WEIGHTED ? (double)weights[e] : 1.0;
                 if (du + w == dv && (du < dp || (du == dp && u < p))) { dp = du; p = u; }
             }
         }
-        pred[((size_t)b * n + v) * SB + lane] = p;
+        pred[i] = p;
     }
 }
 
@@ -209,10 +257,20 @@ struct MultiWs {
     int32_t *src_pad;
 };
 
-size_t multi_bytes(int32_t n, int32_t nb, bool with_pred) {
-    size_t b = geo::align_up((size_t)nb * n * SB * sizeof(double));
-    if (with_pred) b += geo::align_up((size_t)nb * n * SB * sizeof(int32_t));
-    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + geo::align_up((size_t)nb * SB * sizeof(int32_t));
+// sources per batch.  64 (one 512-byte row per node and wave, CSR row through the scalar cache) is the
+// fastest layout measured on MI355X at every graph size: a 16-source batch would fit one XCD's L2 at
+// N=60 000, but its per-lane addressing and four CSR rows per wave cost more than the L2 hits return
+// (7-10 TB/s of gathered bytes against 9-19 TB/s).  16 is kept for calls with few sources, where it
+// avoids relaxing padded lanes.
+int choose_sb(int32_t n, int32_t n_sources) {
+    (void)n;
+    return n_sources <= 16 ? 16 : 64;
+}
+
+size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
+    size_t b = geo::align_up((size_t)nb * n * sb * sizeof(double));
+    if (with_pred) b += geo::align_up((size_t)nb * n * sb * sizeof(int32_t));
+    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + geo::align_up((size_t)nb * sb * sizeof(int32_t));
     return b;
 }
 
@@ -220,9 +278,13 @@ size_t multi_bytes(int32_t n, int32_t nb, bool with_pred) {
 
 extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources) {
     if (n < 0 || n_sources < 0) return 0;
-    const int32_t nb = (n_sources + SB - 1) / SB;
-    size_t multi = multi_bytes(n > 0 ? n : 1, nb > 0 ? nb : 1, true);
-    size_t single = geo::align_up((size_t)(n > 0 ? n : 1) * sizeof(double)) + 256;
+    const int32_t nn = n > 0 ? n : 1, ss = n_sources > 0 ? n_sources : 1;
+    size_t multi = 0;
+    for (int sb : {16, 64}) {
+        const size_t m = multi_bytes(nn, (ss + sb - 1) / sb, sb, true);
+        multi = m > multi ? m : multi;
+    }
+    size_t single = geo::align_up((size_t)nn * sizeof(double)) + 256;
     return (multi > single ? multi : single) + 1024;
 }
 
@@ -233,27 +295,30 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     GEO_REQUIRE(n > 0 && n_sources > 0, "geo_sssp_multi: n=%d n_sources=%d must be positive", n, n_sources);
     GEO_REQUIRE(indptr && indices && sources && ws, "geo_sssp_multi: null pointer");
-    const int32_t nb = (n_sources + SB - 1) / SB;
-    if (ws_bytes < multi_bytes(n, nb, P_out != nullptr)) {
-        geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes, multi_bytes(n, nb, P_out != nullptr));
+    const int sb = choose_sb(n, n_sources);
+    const int32_t nb = (n_sources + sb - 1) / sb;
+    if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr)) {
+        geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes, multi_bytes(n, nb, sb, P_out != nullptr));
         return GEO_E_WORKSPACE;
     }
     geo::Arena ar(ws, ws_bytes);
     MultiWs w;
-    w.dist = ar.take<double>((size_t)nb * n * SB);
-    w.pred = P_out ? ar.take<int32_t>((size_t)nb * n * SB) : nullptr;
+    w.dist = ar.take<double>((size_t)nb * n * sb);
+    w.pred = P_out ? ar.take<int32_t>((size_t)nb * n * sb) : nullptr;
     w.flags = ar.take<int32_t>(3 * (size_t)nb);
-    w.src_pad = ar.take<int32_t>((size_t)nb * SB);
+    w.src_pad = ar.take<int32_t>((size_t)nb * sb);
 
-    GEO_HIP_CHECK(hipMemsetAsync(w.src_pad, 0xff, (size_t)nb * SB * sizeof(int32_t), stream));   // -1 = no source
+    GEO_HIP_CHECK(hipMemsetAsync(w.src_pad, 0xff, (size_t)nb * sb * sizeof(int32_t), stream));   // -1 = no source
     GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, sources, (size_t)n_sources * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)nb * sizeof(int32_t), stream));
-    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * SB, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb);
+    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
     GEO_LAUNCH_CHECK();
 
-    // grid: a multiple of nb so that block -> (batch, node slice) is exact
-    const int per_batch = geo::grid_for(n, WAVES_PER_BLOCK, nb >= 8192 ? 1 : 8192 / nb);
-    const unsigned grid = (unsigned)per_batch * (unsigned)nb;
+    // blocks per batch: enough to cover the nodes, capped so that one sweep stays <= ~64k blocks
+    const int nodes_per_block = (64 / sb) * WAVES_PER_BLOCK;
+    const int groups = (nb + 7) / 8;
+    int per_batch = geo::grid_for(n, nodes_per_block, 8192 / groups > 0 ? 8192 / groups : 1);
+    const unsigned grid = (unsigned)per_batch * 8u * (unsigned)groups;
     std::vector<int32_t> hflags(nb);
     int32_t sweeps = 0;
     bool done = false;
@@ -268,12 +333,12 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
         for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
             const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
-            if (weights)
-                sweep_multi_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.flags,
-                                                                   prev, cur, next, sweeps == 0);
-            else
-                sweep_multi_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.flags,
-                                                                    prev, cur, next, sweeps == 0);
+#define GEO_SWEEP(SBT, WT)                                                                                          \
+    sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, w.dist, w.flags, \
+                                                          prev, cur, next, sweeps == 0)
+            if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
+            else          { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
+#undef GEO_SWEEP
             GEO_LAUNCH_CHECK();
             last_cur = cur;
         }
@@ -296,22 +361,22 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {
-        transpose_out_kernel<double, float><<<tgrid, 256, 0, stream>>>(w.dist, D_out, n, n_sources);
+        transpose_out_kernel<double, float><<<tgrid, 256, 0, stream>>>(w.dist, D_out, n, n_sources, sb);
         GEO_LAUNCH_CHECK();
     }
     if (P_out) {
-        const dim3 pgrid((unsigned)geo::grid_for(n, WAVES_PER_BLOCK, 4096), (unsigned)nb);
+        const int pg = geo::grid_for((int64_t)nb * n * sb, 256, 8192);
         if (weights)
-            pred_multi_kernel<true><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.src_pad, w.pred);
+            pred_multi_kernel<true><<<pg, 256, 0, stream>>>(indptr, indices, weights, n, nb, sb, w.dist, w.src_pad, w.pred);
         else
-            pred_multi_kernel<false><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, w.src_pad, w.pred);
+            pred_multi_kernel<false><<<pg, 256, 0, stream>>>(indptr, indices, weights, n, nb, sb, w.dist, w.src_pad, w.pred);
         GEO_LAUNCH_CHECK();
-        transpose_out_kernel<int32_t, int32_t><<<tgrid, 256, 0, stream>>>(w.pred, P_out, n, n_sources);
+        transpose_out_kernel<int32_t, int32_t><<<tgrid, 256, 0, stream>>>(w.pred, P_out, n, n_sources, sb);
         GEO_LAUNCH_CHECK();
     }
     if (dmin_out || argmin_out) {
         colmin_kernel<<<(unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), 256, 0, stream>>>(
-            w.dist, n, nb, n_sources, dmin_out, argmin_out);
+            w.dist, n, n_sources, sb, dmin_out, argmin_out);
         GEO_LAUNCH_CHECK();
     }
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
