@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void init_multi_kernel(double *__restrict__ di
 //
 // A wave relaxes 64/SBT nodes for the SBT sources of one batch (lane = node slot * SBT + source): each
 // neighbour row is one SBT*8-byte contiguous read.  Block order is batch-group major: blocks
-// [g*8*P, (g+1)*8*P) cover batches 8g .. 8g+7 with batch = 8g + (bid % 8).  Blocks are dealt round-robin
+// [g*8*P, (g+1)*8*P) cover batches 8g .. 8g+7 with batch = 8g + (bid % 8) (fewer than 8 batches: bid % nb).  Blocks are dealt round-robin
 // over the 8 XCDs and dispatched in order, so at any moment one XCD's L2 works on ONE batch whose
 // n*SBT*8 bytes of distances it can hold (4 MiB L2): every row is re-read ~deg times per sweep from L2
 // instead of the Infinity Cache (measured 17-19 TB/s vs 9 TB/s of gathered bytes).  Placement is a
@@ -73,16 +73,16 @@ template <int SBT, bool WEIGHTED>
 __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restrict__ indptr,
                                                          const int32_t *__restrict__ indices,
                                                          const float *__restrict__ weights, int32_t n, int32_t nb,
-                                                         int32_t blocks_per_batch, double *dist, int32_t *flags,
-                                                         int prev, int cur, int next, int first) {
+                                                         int32_t blocks_per_batch, int32_t gs, double *dist,
+                                                         int32_t *flags, int prev, int cur, int next, int first) {
     constexpr int NPW = 64 / SBT;            // nodes per wave
     constexpr int NPB = NPW * WAVES_PER_BLOCK;
     const int bid = blockIdx.x;
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
-    const int group = bid / (8 * blocks_per_batch);
-    const int b = group * 8 + (bid & 7);
-    const int xb = (bid % (8 * blocks_per_batch)) >> 3;
+    const int group = bid / (gs * blocks_per_batch);          // gs = min(nb, 8) batches share a block group
+    const int b = group * gs + (bid % gs);
+    const int xb = (bid % (gs * blocks_per_batch)) / gs;
     if (b >= nb) return;
     if (!first && flags[prev * nb + b] == 0) return;   // this batch already reached its fixed point
 
@@ -316,9 +316,11 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
 
     // blocks per batch: enough to cover the nodes, capped so that one sweep stays <= ~64k blocks
     const int nodes_per_block = (64 / sb) * WAVES_PER_BLOCK;
-    const int groups = (nb + 7) / 8;
-    int per_batch = geo::grid_for(n, nodes_per_block, 8192 / groups > 0 ? 8192 / groups : 1);
-    const unsigned grid = (unsigned)per_batch * 8u * (unsigned)groups;
+    const int gs = nb < 8 ? nb : 8;
+    const int groups = (nb + gs - 1) / gs;
+    const int cap = 65536 / (gs * groups);
+    const int per_batch = geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
+    const unsigned grid = (unsigned)per_batch * (unsigned)gs * (unsigned)groups;
     std::vector<int32_t> hflags(nb);
     int32_t sweeps = 0;
     bool done = false;
@@ -334,7 +336,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
             const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
 #define GEO_SWEEP(SBT, WT)                                                                                          \
-    sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, w.dist, w.flags, \
+    sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, gs, w.dist, w.flags, \
                                                           prev, cur, next, sweeps == 0)
             if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
             else          { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
