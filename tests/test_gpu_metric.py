@@ -115,3 +115,22 @@ def test_generic_decoder_properties_on_gpu():
     zi, zj = _pairs(M=127, device="cuda")
     assert torch.allclose(edge_lengths_riemannian(dec, zi, zj, batch_size=16),
                           edge_lengths_riemannian(dec, zi, zj, batch_size=1024), rtol=1e-5, atol=1e-7)
+
+
+def test_groupnorm_decoder_takes_the_autograd_path(golden):
+    """GroupNorm is outside the kernels' coverage: the drop-in still answers (autograd on the GPU, the
+    reference's own method) and matches the reference's golden lengths."""
+    from oracle import metric as om
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    from vqvae_amd.spatial_decoder import SpatialDecoder, hip_kernels_cover
+    sd = om.make_decoder_state(12, 16, 1, norm_type="group")
+    dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "group")
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert not hip_kernels_cover(dec)
+    r = np.random.RandomState(112)
+    zs = r.randn(E, 16).astype(np.float32)
+    ze = (zs + 0.3 * r.randn(E, 16)).astype(np.float32)
+    L = edge_lengths_riemannian(dec.cuda().eval(), torch.from_numpy(zs[:512]), torch.from_numpy(ze[:512]), batch_size=512)
+    ref = golden("metric")["fm_group/train0/bs512"][:512]
+    rel = np.abs(L.cpu().numpy() - ref) / ref
+    assert L.is_cuda and np.mean(rel <= 1e-5) >= 0.99

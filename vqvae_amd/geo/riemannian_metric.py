@@ -5,14 +5,14 @@ For decoders with the SpatialDecoder layer layout the Jacobian-vector products r
 kernels of csrc/jvp.hip (forward-mode tangent propagation, MFMA for the dominant ConvT layer),
 chunked by `batch_size` exactly like riemannian_metric.py:50-58 so that train-mode BatchNorm sees
 the same batches.  Any other nn.Module (e.g. the Linear test decoder of the reference's
-tests/test_riemannian_metric.py, or the vanilla VAE decoder) has no kernel: it is differentiated
-with torch.func.jvp on the decoder's own device.
+tests/test_riemannian_metric.py, the vanilla VAE decoder, or a SpatialDecoder variant outside the kernels'
+coverage such as GroupNorm) has no kernel: it is differentiated by autograd on the decoder's own device.
 """
 import torch
 
 from .. import _lib
 from .._device import device, ptr, stream_ptr, workspace
-from ..spatial_decoder import DecoderExport, looks_like_spatial_decoder
+from ..spatial_decoder import DecoderExport, hip_kernels_cover, looks_like_spatial_decoder
 
 
 @torch.no_grad()
@@ -60,7 +60,8 @@ def edge_lengths_graph_device(export: DecoderExport, z: torch.Tensor, src: torch
 
 
 def _generic_jvp_norms(decoder, z: torch.Tensor, direction: torch.Tensor) -> torch.Tensor:
-    """|J(z) v| for an arbitrary decoder by forward-mode AD (no kernel exists for it).
+    """|J(z) v| for a decoder the kernels cannot represent, by autograd on the decoder's own device
+    (works for any module, including train-mode BatchNorm with its running-statistic updates).
     Linear-first decoders take 2-D input, conv-first ones a 1x1 latent image (riemannian_metric.py:18-27)."""
     first = next(decoder.children())
     flat_input = hasattr(first, "in_features")
@@ -70,7 +71,7 @@ def _generic_jvp_norms(decoder, z: torch.Tensor, direction: torch.Tensor) -> tor
             latent = latent[:, :, None, None]
         return torch.sigmoid(decoder(latent)).flatten(1)
 
-    _, tangent = torch.func.jvp(image, (z,), (direction,))
+    _, tangent = torch.autograd.functional.jvp(image, (z,), (direction,))
     return torch.linalg.vector_norm(tangent, dim=1)
 
 
@@ -79,7 +80,7 @@ def edge_lengths_riemannian(decoder, z_start: torch.Tensor, z_end: torch.Tensor,
     """0.5 * (|J(z_i) dz| + |J(z_j) dz|) per edge, float32, on the decoder's device (riemannian_metric.py:37-66)."""
     assert z_start.shape == z_end.shape, "Start and end points must have same shape"
     dec_dev = next(decoder.parameters()).device
-    if looks_like_spatial_decoder(decoder) and z_start.ndim == 2:
+    if looks_like_spatial_decoder(decoder) and z_start.ndim == 2 and hip_kernels_cover(decoder):
         dev = dec_dev if dec_dev.type == "cuda" else device()
         export = DecoderExport(decoder, dev)
         zs = z_start.detach().to(dev, torch.float32).contiguous()

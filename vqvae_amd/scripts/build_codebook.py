@@ -24,9 +24,9 @@ from .._device import DeviceCSR, device
 from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
                                        upper_edges_device)
-from ..geo.riemannian_metric import edge_lengths_graph_device
+from ..geo.riemannian_metric import edge_lengths_graph_device, edge_lengths_riemannian
 from ..parallel import sharded_edge_lengths
-from ..spatial_decoder import DecoderExport, load_decoder_from_checkpoint
+from ..spatial_decoder import DecoderExport, hip_kernels_cover, load_decoder_from_checkpoint
 
 
 def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: str = "union", K: int = 512,
@@ -50,11 +50,14 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
     t0 = tick("knn", t0)
 
     print(f"Re-weighting {src.numel()} edges using Riemannian metric...")
-    export = DecoderExport(decoder, dev)
-    # whole chunks of `batch_size` edges per rank: every BatchNorm batch stays intact
-    lengths = sharded_edge_lengths(
-        int(src.numel()), batch_size,
-        lambda e0, e1: edge_lengths_graph_device(export, z_flat, src[e0:e1], dst[e0:e1], batch_size), group)
+    if hip_kernels_cover(decoder):
+        export = DecoderExport(decoder, dev)
+        # whole chunks of `batch_size` edges per rank: every BatchNorm batch stays intact
+        lengths = sharded_edge_lengths(
+            int(src.numel()), batch_size,
+            lambda e0, e1: edge_lengths_graph_device(export, z_flat, src[e0:e1], dst[e0:e1], batch_size), group)
+    else:       # e.g. GroupNorm: no kernel, autograd on the GPU (the reference's own method)
+        lengths = edge_lengths_riemannian(decoder, z_flat[src.long()], z_flat[dst.long()], batch_size).contiguous()
     t0 = tick("jvp", t0)
 
     W_geo = reweight_device(G, entry_edge, lengths)

@@ -82,6 +82,20 @@ def looks_like_spatial_decoder(m: nn.Module) -> bool:
     return len(kinds) == 1 and kinds <= {nn.BatchNorm2d, nn.GroupNorm, nn.Identity}
 
 
+def hip_kernels_cover(m: nn.Module) -> bool:
+    """Whether csrc/jvp.hip implements this SpatialDecoder-shaped module (else the caller differentiates it
+    with autograd): BatchNorm or no norm, dec_channels[1] in {32,64,128}, dec_channels[2] a multiple of 16
+    dividing 128, latent_dim <= 64, LDS budget of the output stage."""
+    seq = m.deconv_layers
+    if isinstance(seq[1], nn.GroupNorm):
+        return False
+    d, c1, c2, co = m.conv_in.in_channels, seq[0].out_channels, seq[3].out_channels, seq[6].out_channels
+    s_out = 8 if seq[6].padding[0] == 1 else 4
+    back_lds = (2 * 8 * 16 * (c2 + 4) + 16 * co * (c2 + 4) + 8 * co * s_out * s_out) * 4
+    return (d <= 64 and c1 in (32, 64, 128) and c2 % 16 == 0 and 128 % c2 == 0 and back_lds <= 160 * 1024
+            and all(getattr(l, "bias", None) is not None for l in (m.conv_in, seq[0], seq[3], seq[6])))
+
+
 class DecoderExport:
     """f32 contiguous copies of a decoder's parameters on `dev` plus the ctypes descriptor over them."""
 
