@@ -56,11 +56,18 @@ def _norm_push(x, t, sd, prefix, norm_type, training, dtype):
         dims, eps = (2,), GN_EPS
     else:
         raise ValueError(norm_type)
-    mu = xs.mean(dim=dims, keepdim=True)
-    var = ((xs - mu) ** 2).mean(dim=dims, keepdim=True)          # biased, as torch normalises
-    inv = 1.0 / torch.sqrt(var + eps)
+    # statistics are accumulated in float64 and rounded once, like torch's CPU kernels (acc_type<float> is
+    # double there); plain float32 means lose up to 1e-2 on batches with |mean| >> std (few distinct samples)
+    acc = torch.float64
+    mu = xs.to(acc).mean(dim=dims, keepdim=True)
+    var = ((xs.to(acc) - mu) ** 2).mean(dim=dims, keepdim=True)          # biased, as torch normalises
+    inv = (1.0 / torch.sqrt(var + eps))
+    xhat64 = (xs.to(acc) - mu) * inv
+    mean_t = ts.to(acc).mean(dim=dims, keepdim=True)
+    mean_xt = (xhat64 * ts.to(acc)).mean(dim=dims, keepdim=True)
+    mu, inv, mean_t, mean_xt = (v.to(dtype) for v in (mu, inv, mean_t, mean_xt))
     xhat = (xs - mu) * inv
-    that = inv * (ts - ts.mean(dim=dims, keepdim=True) - xhat * (xhat * ts).mean(dim=dims, keepdim=True))
+    that = inv * (ts - mean_t - xhat * mean_xt)
     xhat, that = xhat.reshape(x.shape), that.reshape(x.shape)
     return xhat * gamma + beta, that * gamma
 
