@@ -47,7 +47,7 @@ const char *geo_last_error(void);
  * geo_shortest_paths.py:50.  weights == NULL means unit weights (unweighted=True, :32-34).
  * Unreachable = +inf; predecessor sentinel -9999.
  * ------------------------------------------------------------------------------------------ */
-size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources);
+size_t geo_sssp_workspace_bytes(int32_t n, int64_t nnz, int32_t n_sources);
 
 /* S sources -> any of: D_out f32 [S][n]; P_out i32 [S][n]; dmin_out f32 [n] + argmin_out i32 [n]
  * (column minimum over the S rows of the f32 matrix and the FIRST row index attaining it,
@@ -55,7 +55,7 @@ size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources);
  * sweeps_out [host, may be NULL] receives the number of relaxation sweeps launched.
  * Synchronises. */
 int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights,
-                   int32_t n, const int32_t *sources, int32_t n_sources,
+                   int32_t n, int64_t nnz, const int32_t *sources, int32_t n_sources,
                    float *D_out, int32_t *P_out, float *dmin_out, int32_t *argmin_out,
                    void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 

@@ -21,6 +21,7 @@
 #include "sssp_device.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -37,12 +38,16 @@ __device__ __forceinline__ int row_bcast(int x) {
 }
 
 // One step of the 16-source relaxation: edge J of the 16 edges held one per lane in (idx, wbits).
+// Unconditional (lanes past the row end carry the node itself with weight +inf), so the 16 gathers of a
+// chunk are independent loads in flight together; 32-bit element offsets keep the address math to one op.
 template <int J>
-__device__ __forceinline__ void relax_edge16(const double *__restrict__ D, int s, int idx, int wbits, int32_t cnt,
-                                             double &best) {
-    const int32_t u = row_bcast<J>(idx);
+__device__ __forceinline__ void relax_edge16(const double *__restrict__ D, unsigned s, int idx, int wbits, double &best) {
+    const unsigned u = (unsigned)row_bcast<J>(idx);
     const float w = __int_as_float(row_bcast<J>(wbits));
-    if (J < cnt) best = fmin(best, D[(size_t)u * 16 + s] + (double)w);
+    // 32-bit BYTE offset from the (wave-uniform) batch base: scalar base + one VGPR offset, no 64-bit VALU math
+    const unsigned off = (u << 7) | (s << 3);
+    const double du = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(D) + off);
+    best = fmin(best, du + (double)w);
 }
 
 // ------------------------------------------------------------------------------------ multi-source
@@ -103,19 +108,30 @@ __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restr
             // columns and weights, then share them lane by lane through DPP: one gather per edge remains
             for (int32_t e = e0; e < e1; e += 16) {
                 const int32_t cnt = e1 - e;                        // uniform inside the slot
-                const int idx = (s < cnt) ? indices[e + s] : 0;
-                const int wb = (s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0;
-                relax_edge16<0>(D, s, idx, wb, cnt, best); relax_edge16<1>(D, s, idx, wb, cnt, best);
-                relax_edge16<2>(D, s, idx, wb, cnt, best); relax_edge16<3>(D, s, idx, wb, cnt, best);
-                relax_edge16<4>(D, s, idx, wb, cnt, best); relax_edge16<5>(D, s, idx, wb, cnt, best);
-                relax_edge16<6>(D, s, idx, wb, cnt, best); relax_edge16<7>(D, s, idx, wb, cnt, best);
-                relax_edge16<8>(D, s, idx, wb, cnt, best); relax_edge16<9>(D, s, idx, wb, cnt, best);
-                relax_edge16<10>(D, s, idx, wb, cnt, best); relax_edge16<11>(D, s, idx, wb, cnt, best);
-                relax_edge16<12>(D, s, idx, wb, cnt, best); relax_edge16<13>(D, s, idx, wb, cnt, best);
-                relax_edge16<14>(D, s, idx, wb, cnt, best); relax_edge16<15>(D, s, idx, wb, cnt, best);
+                const int idx = (s < cnt) ? indices[e + s] : v;    // padding: the node itself ...
+                const int wb = (s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000)
+                                         : 0x7f800000;             // ... at distance +inf (no effect)
+                const unsigned us = (unsigned)s;
+                relax_edge16<0>(D, us, idx, wb, best); relax_edge16<1>(D, us, idx, wb, best);
+                relax_edge16<2>(D, us, idx, wb, best); relax_edge16<3>(D, us, idx, wb, best);
+                relax_edge16<4>(D, us, idx, wb, best); relax_edge16<5>(D, us, idx, wb, best);
+                relax_edge16<6>(D, us, idx, wb, best); relax_edge16<7>(D, us, idx, wb, best);
+                relax_edge16<8>(D, us, idx, wb, best); relax_edge16<9>(D, us, idx, wb, best);
+                relax_edge16<10>(D, us, idx, wb, best); relax_edge16<11>(D, us, idx, wb, best);
+                relax_edge16<12>(D, us, idx, wb, best); relax_edge16<13>(D, us, idx, wb, best);
+                relax_edge16<14>(D, us, idx, wb, best); relax_edge16<15>(D, us, idx, wb, best);
             }
         } else {
+            // 16 neighbour rows in flight per wave: the sweep is bound by gather latency x occupancy, not by
+            // bytes, so memory-level parallelism per wave is what moves it
             int32_t e = e0;
+            for (; e + 16 <= e1; e += 16) {
+                double dd[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) dd[j] = D[(size_t)indices[e + j] * SBT + s];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) best = fmin(best, dd[j] + (WEIGHTED ? (double)weights[e + j] : 1.0));
+            }
             for (; e + 4 <= e1; e += 4) {
                 const int32_t u0 = indices[e], u1 = indices[e + 1], u2 = indices[e + 2], u3 = indices[e + 3];
                 const double d0 = D[(size_t)u0 * SBT + s], d1 = D[(size_t)u1 * SBT + s];
@@ -131,6 +147,78 @@ __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restr
         }
         if (best < curv) {
             D[(size_t)v * SBT + s] = best;
+            any = true;
+        }
+    }
+    if (__any(any) && lane == 0) flags[cur * nb + b] = 1;
+}
+
+// ---- 16-source batches, work item = one 16-edge chunk of one node's row -------------------------
+// With 16 sources per batch a batch's distances are n*128 bytes: at N = 60 000 that is 7.7 MB, which one
+// XCD's L2 serves at ~17 TB/s of gathered bytes, against ~9 TB/s from the Infinity Cache for 64-source
+// batches (30.7 MB).  Rows are cut into 16-edge chunks so that the four 16-lane slots of a wave always have
+// the same trip count (node degrees range from k to several hundred); a chunk's minimum is folded into
+// the node's distance with a 64-bit atomicMin on the bit pattern (non-negative doubles order like
+// unsigned integers), which keeps the in-place, only-decreasing update rule of the plain sweep.
+__global__ __launch_bounds__(256) void chunk_count_kernel(const int32_t *__restrict__ indptr, int32_t n,
+                                                         int32_t *__restrict__ cnt) {
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+        cnt[v] = (indptr[v + 1] - indptr[v] + 15) >> 4;
+}
+
+__global__ __launch_bounds__(256) void chunk_fill_kernel(const int32_t *__restrict__ indptr, int32_t n,
+                                                        const int32_t *__restrict__ chunk_off,
+                                                        int32_t *__restrict__ chunk_node,
+                                                        int32_t *__restrict__ chunk_start) {
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const int32_t c0 = chunk_off[v], c1 = chunk_off[v + 1];
+        for (int32_t c = c0; c < c1; ++c) {
+            chunk_node[c] = v;
+            chunk_start[c] = indptr[v] + ((c - c0) << 4);
+        }
+    }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                           const int32_t *__restrict__ chunk_node,
+                                                           const int32_t *__restrict__ chunk_start, int32_t n_chunks,
+                                                           int32_t blocks_per_batch, int32_t gs, double *dist,
+                                                           int32_t *flags, int prev, int cur, int next, int first) {
+    const int bid = blockIdx.x;
+    if (bid == 0)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
+    const int group = bid / (gs * blocks_per_batch);
+    const int b = group * gs + (bid % gs);
+    const int xb = (bid % (gs * blocks_per_batch)) / gs;
+    if (b >= nb) return;
+    if (!first && flags[prev * nb + b] == 0) return;
+
+    const int lane = threadIdx.x & 63;
+    const int slot_in_block = threadIdx.x >> 4;              // 16 slots of 16 lanes per block
+    const unsigned s = lane & 15;
+    double *D = dist + (size_t)b * n * 16;
+    unsigned long long *Dbits = reinterpret_cast<unsigned long long *>(D);
+    bool any = false;
+    for (int32_t c = xb * 16 + slot_in_block; c < n_chunks; c += blocks_per_batch * 16) {
+        const int32_t v = chunk_node[c], e = chunk_start[c];
+        const int32_t cnt = indptr[v + 1] - e;               // >= 1; more than 16 means further chunks follow
+        const int idx = ((int)s < cnt) ? indices[e + s] : v;
+        const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+        const double curv = D[(unsigned)v * 16u + s];
+        double best = curv;
+        relax_edge16<0>(D, s, idx, wb, best); relax_edge16<1>(D, s, idx, wb, best);
+        relax_edge16<2>(D, s, idx, wb, best); relax_edge16<3>(D, s, idx, wb, best);
+        relax_edge16<4>(D, s, idx, wb, best); relax_edge16<5>(D, s, idx, wb, best);
+        relax_edge16<6>(D, s, idx, wb, best); relax_edge16<7>(D, s, idx, wb, best);
+        relax_edge16<8>(D, s, idx, wb, best); relax_edge16<9>(D, s, idx, wb, best);
+        relax_edge16<10>(D, s, idx, wb, best); relax_edge16<11>(D, s, idx, wb, best);
+        relax_edge16<12>(D, s, idx, wb, best); relax_edge16<13>(D, s, idx, wb, best);
+        relax_edge16<14>(D, s, idx, wb, best); relax_edge16<15>(D, s, idx, wb, best);
+        if (best < curv) {
+            atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
             any = true;
         }
     }
@@ -263,8 +351,20 @@ struct MultiWs {
 // (7-10 TB/s of gathered bytes against 9-19 TB/s).  16 is kept for calls with few sources, where it
 // avoids relaxing padded lanes.
 int choose_sb(int32_t n, int32_t n_sources) {
-    (void)n;
-    return n_sources <= 16 ? 16 : 64;
+    if (const char *e = getenv("GEO_SSSP_SB")) {          // experiment switch (bench/tests leave it unset)
+        const int v = atoi(e);
+        if (v == 16 || v == 64) return v;
+    }
+    if (n_sources <= 16) return 16;
+    // 16-source batches pay off while one batch (n * 128 bytes) stays within reach of an XCD's 4 MiB L2
+    if (n_sources >= 32 && (size_t)n * 128 <= ((size_t)12 << 20) && (size_t)n * 512 > ((size_t)6 << 20)) return 16;
+    return 64;
+}
+
+size_t chunk_bytes(int32_t n, int64_t nnz) {
+    const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
+    return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
+           geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1));
 }
 
 size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
@@ -276,20 +376,21 @@ size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
 
 }  // namespace
 
-extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int32_t n_sources) {
-    if (n < 0 || n_sources < 0) return 0;
+extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int64_t nnz, int32_t n_sources) {
+    if (n < 0 || n_sources < 0 || nnz < 0) return 0;
     const int32_t nn = n > 0 ? n : 1, ss = n_sources > 0 ? n_sources : 1;
     size_t multi = 0;
     for (int sb : {16, 64}) {
         const size_t m = multi_bytes(nn, (ss + sb - 1) / sb, sb, true);
         multi = m > multi ? m : multi;
     }
+    multi += chunk_bytes(nn, nnz);
     size_t single = geo::align_up((size_t)nn * sizeof(double)) + 256;
     return (multi > single ? multi : single) + 1024;
 }
 
 extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
-                              const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
+                              int64_t nnz, const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
                               float *dmin_out, int32_t *argmin_out, void *ws, size_t ws_bytes,
                               int32_t *sweeps_out, void *stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -297,8 +398,11 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     GEO_REQUIRE(indptr && indices && sources && ws, "geo_sssp_multi: null pointer");
     const int sb = choose_sb(n, n_sources);
     const int32_t nb = (n_sources + sb - 1) / sb;
-    if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr)) {
-        geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes, multi_bytes(n, nb, sb, P_out != nullptr));
+    const bool chunked = sb == 16 && n_sources > 16;       // 16-edge chunk work items (see sweep_chunk16_kernel)
+    GEO_REQUIRE(nnz >= 0, "geo_sssp_multi: nnz must be given");
+    if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz) : 0)) {
+        geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes,
+                       multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz) : 0));
         return GEO_E_WORKSPACE;
     }
     geo::Arena ar(ws, ws_bytes);
@@ -314,12 +418,31 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
     GEO_LAUNCH_CHECK();
 
-    // blocks per batch: enough to cover the nodes, capped so that one sweep stays <= ~64k blocks
+    int32_t *chunk_node = nullptr, *chunk_start = nullptr;
+    int64_t n_chunks = 0;
+    if (chunked) {
+        int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
+        const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
+        chunk_node = ar.take<int32_t>(max_chunks);
+        chunk_start = ar.take<int32_t>(max_chunks);
+        const size_t sbytes = geo::scan_tmp_bytes((int64_t)n + 1);
+        void *stmp = ar.take<char>(sbytes);
+        GEO_REQUIRE(stmp != nullptr, "geo_sssp_multi: workspace carve failed");
+        chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
+        GEO_LAUNCH_CHECK();
+        int rc = geo::exclusive_scan_i32(ccnt, coff, n, stmp, sbytes, &n_chunks, stream);
+        if (rc) return rc;
+        GEO_REQUIRE((size_t)n_chunks <= max_chunks, "geo_sssp_multi: nnz=%lld does not match the graph", (long long)nnz);
+        chunk_fill_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, coff, chunk_node, chunk_start);
+        GEO_LAUNCH_CHECK();
+    }
+    // blocks per batch: enough to cover the work items, capped so that one sweep stays <= ~64k blocks
     const int nodes_per_block = (64 / sb) * WAVES_PER_BLOCK;
     const int gs = nb < 8 ? nb : 8;
     const int groups = (nb + gs - 1) / gs;
     const int cap = 65536 / (gs * groups);
-    const int per_batch = geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
+    const int per_batch = chunked ? geo::grid_for(n_chunks, 16, cap > 0 ? cap : 1)
+                                  : geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
     const unsigned grid = (unsigned)per_batch * (unsigned)gs * (unsigned)groups;
     std::vector<int32_t> hflags(nb);
     int32_t sweeps = 0;
@@ -338,8 +461,17 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
 #define GEO_SWEEP(SBT, WT)                                                                                          \
     sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, gs, w.dist, w.flags, \
                                                           prev, cur, next, sweeps == 0)
-            if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
-            else          { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
+            if (chunked) {
+                if (weights)
+                    sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
+                                                                         (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
+                                                                         prev, cur, next, sweeps == 0);
+                else
+                    sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
+                                                                          (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
+                                                                          prev, cur, next, sweeps == 0);
+            } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
+            else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
             GEO_LAUNCH_CHECK();
             last_cur = cur;

@@ -59,11 +59,11 @@ def sssp_multi_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool =
     P = torch.empty((S, n), dtype=torch.int32, device=dev) if want_P else None
     dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_min else None
     amin = torch.empty(n, dtype=torch.int32, device=dev) if want_min else None
-    ws = workspace(lib.geo_sssp_workspace_bytes(n, S), dev)
+    ws = workspace(lib.geo_sssp_workspace_bytes(n, G.nnz, S), dev)
     sweeps = np.zeros(1, dtype=np.int32)
     weights = None if unweighted else G.data
     with torch.cuda.device(dev):
-        _lib.check(lib.geo_sssp_multi(ptr(G.indptr), ptr(G.indices), ptr(weights), n, ptr(sources), S,
+        _lib.check(lib.geo_sssp_multi(ptr(G.indptr), ptr(G.indices), ptr(weights), n, G.nnz, ptr(sources), S,
                                       ptr(D), ptr(P), ptr(dmin), ptr(amin), ptr(ws), ws.numel(),
                                       sweeps.ctypes.data, stream_ptr()), "geo_sssp_multi")
     return D, P, dmin, amin, int(sweeps[0])

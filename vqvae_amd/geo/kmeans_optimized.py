@@ -35,7 +35,7 @@ class _Chain:
         dev = G.indptr.device
         self.dmin = torch.full((G.n,), float("inf"), dtype=torch.float32, device=dev)
         self.arg = torch.zeros(G.n, dtype=torch.int32, device=dev)
-        self.ws = workspace(self.lib.geo_sssp_workspace_bytes(G.n, 1), dev)
+        self.ws = workspace(self.lib.geo_sssp_workspace_bytes(G.n, G.nnz, 1), dev)
         self.host = torch.empty(G.n, dtype=torch.float32, pin_memory=True)
         self.sweeps = 0
         self.solves = 0
