@@ -179,6 +179,15 @@ __global__ __launch_bounds__(256) void chunk_fill_kernel(const int32_t *__restri
     }
 }
 
+__global__ __launch_bounds__(256) void source_bits_kernel(const int32_t *__restrict__ src, int32_t n_sources, int32_t n,
+                                                         int32_t sb, int32_t words, uint32_t *__restrict__ bits) {
+    uint8_t *map = reinterpret_cast<uint8_t *>(bits);                    // one byte per (batch, node)
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sources; i += gridDim.x * blockDim.x) {
+        const int32_t v = src[i];
+        if (v >= 0 && v < n) map[(size_t)(i / sb) * words * 4 + v] = 1;
+    }
+}
+
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
@@ -186,7 +195,10 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
                                                            const int32_t *__restrict__ chunk_node,
                                                            const int32_t *__restrict__ chunk_start, int32_t n_chunks,
                                                            int32_t blocks_per_batch, int32_t gs, double *dist,
-                                                           int32_t *flags, int prev, int cur, int next, int first) {
+                                                           int32_t *flags, int32_t *counts,
+                                                           const uint32_t *__restrict__ bits_prev,
+                                                           uint32_t *__restrict__ bits_cur, int32_t words, int prev,
+                                                           int cur, int next, int first, int act_mode) {
     const int bid = blockIdx.x;
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
@@ -194,35 +206,88 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     const int b = group * gs + (bid % gs);
     const int xb = (bid % (gs * blocks_per_batch)) / gs;
     if (b >= nb) return;
-    if (!first && flags[prev * nb + b] == 0) return;
+    if (!first && flags[prev * nb + b] == 0) return;                     // fixed point reached for this batch
+    // the neighbour-activity test only pays when few rows moved (first sweeps, last sweeps): `counts` holds a
+    // 1-in-16 block sample of the number of improved chunk slots of the previous sweep
+    // counts[.] >= 0: sampled count, map written;  < 0: -(sampled count), map NOT written by that sweep
+    const int32_t cp = first ? 0 : counts[prev * nb + b];
+    const int32_t est_prev = (cp >= 0 ? cp : -cp) * 16;
+    const bool sparse_sweep = act_mode && (first || (cp >= 0 && est_prev < (n >> 3) * 16));
+    // the activity map costs a scattered byte store per improved slot: keep it only while few rows move
+    const bool write_map = act_mode && (first || est_prev < (n >> 1) * 16);
+    if (bid == 0)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[next * nb + i] = 0;
 
     const int lane = threadIdx.x & 63;
     const int slot_in_block = threadIdx.x >> 4;              // 16 slots of 16 lanes per block
     const unsigned s = lane & 15;
     double *D = dist + (size_t)b * n * 16;
     unsigned long long *Dbits = reinterpret_cast<unsigned long long *>(D);
-    bool any = false;
-    for (int32_t c = xb * 16 + slot_in_block; c < n_chunks; c += blocks_per_batch * 16) {
-        const int32_t v = chunk_node[c], e = chunk_start[c];
-        const int32_t cnt = indptr[v + 1] - e;               // >= 1; more than 16 means further chunks follow
-        const int idx = ((int)s < cnt) ? indices[e + s] : v;
-        const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
-        const double curv = D[(unsigned)v * 16u + s];
-        double best = curv;
-        relax_edge16<0>(D, s, idx, wb, best); relax_edge16<1>(D, s, idx, wb, best);
-        relax_edge16<2>(D, s, idx, wb, best); relax_edge16<3>(D, s, idx, wb, best);
-        relax_edge16<4>(D, s, idx, wb, best); relax_edge16<5>(D, s, idx, wb, best);
-        relax_edge16<6>(D, s, idx, wb, best); relax_edge16<7>(D, s, idx, wb, best);
-        relax_edge16<8>(D, s, idx, wb, best); relax_edge16<9>(D, s, idx, wb, best);
-        relax_edge16<10>(D, s, idx, wb, best); relax_edge16<11>(D, s, idx, wb, best);
-        relax_edge16<12>(D, s, idx, wb, best); relax_edge16<13>(D, s, idx, wb, best);
-        relax_edge16<14>(D, s, idx, wb, best); relax_edge16<15>(D, s, idx, wb, best);
-        if (best < curv) {
-            atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
-            any = true;
+    // activity: a chunk is re-evaluated only if one of its 16 neighbours had a distance lowered (for any of
+    // this batch's 16 sources) during the previous sweep.  Every change is followed by an evaluation of its
+    // dependents in the next sweep, so the fixed point is the same; sweeps 1-2 and the last ones touch a
+    // small part of the graph.  One byte per (batch, node); `bits_prev` was filled by the previous sweep.
+    // (a byte per node, set with plain idempotent stores: no atomics on a few hot cache lines)
+    const uint8_t *bp = reinterpret_cast<const uint8_t *>(bits_prev) + (size_t)b * words * 4;
+    uint8_t *bc = reinterpret_cast<uint8_t *>(bits_cur) + (size_t)b * words * 4;
+    const int slot_in_wave = lane >> 4;
+    int32_t n_better = 0;
+#define GEO_RELAX16_ALL()                                                                                   \
+    relax_edge16<0>(D, s, idx, wb, best); relax_edge16<1>(D, s, idx, wb, best);                             \
+    relax_edge16<2>(D, s, idx, wb, best); relax_edge16<3>(D, s, idx, wb, best);                             \
+    relax_edge16<4>(D, s, idx, wb, best); relax_edge16<5>(D, s, idx, wb, best);                             \
+    relax_edge16<6>(D, s, idx, wb, best); relax_edge16<7>(D, s, idx, wb, best);                             \
+    relax_edge16<8>(D, s, idx, wb, best); relax_edge16<9>(D, s, idx, wb, best);                             \
+    relax_edge16<10>(D, s, idx, wb, best); relax_edge16<11>(D, s, idx, wb, best);                           \
+    relax_edge16<12>(D, s, idx, wb, best); relax_edge16<13>(D, s, idx, wb, best);                           \
+    relax_edge16<14>(D, s, idx, wb, best); relax_edge16<15>(D, s, idx, wb, best)
+    if (sparse_sweep) {
+        // few rows moved last sweep: test the 16 neighbours' activity bytes first, skip idle slots
+        for (int32_t c0 = xb * 16; c0 < n_chunks; c0 += blocks_per_batch * 16) {
+            const int32_t c = c0 + slot_in_block;
+            const bool live = c < n_chunks;
+            const int32_t v = live ? chunk_node[c] : 0, e = live ? chunk_start[c] : 0;
+            const int32_t cnt = live ? indptr[v + 1] - e : 0;
+            const bool has = (int)s < cnt;
+            const int idx = has ? indices[e + s] : v;
+            const bool hot = has && bp[idx] != 0;
+            const unsigned long long hot_mask = __ballot(hot);
+            if (((hot_mask >> (slot_in_wave * 16)) & 0xffffull) == 0) continue;  // whole slot idle this sweep
+            const int wb = has ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+            const double curv = D[(unsigned)v * 16u + s];
+            double best = curv;
+            GEO_RELAX16_ALL();
+            if (best < curv) {
+                atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
+                bc[v] = 1;                                   // same byte for the slot's lanes: one merged store
+                ++n_better;
+            }
+        }
+    } else {
+        // dense sweep: straight-line body, no wave-level votes between a chunk's loads and the next chunk's
+        for (int32_t c = xb * 16 + slot_in_block; c < n_chunks; c += blocks_per_batch * 16) {
+            const int32_t v = chunk_node[c], e = chunk_start[c];
+            const int32_t cnt = indptr[v + 1] - e;           // >= 1; more than 16 means further chunks follow
+            const int idx = ((int)s < cnt) ? indices[e + s] : v;
+            const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+            const double curv = D[(unsigned)v * 16u + s];
+            double best = curv;
+            GEO_RELAX16_ALL();
+            if (best < curv) {
+                atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
+                if (write_map) bc[v] = 1;
+                ++n_better;
+            }
         }
     }
-    if (__any(any) && lane == 0) flags[cur * nb + b] = 1;
+#undef GEO_RELAX16_ALL
+    // n_better counts improved (node, source) pairs of this thread; /16 ~ improved slots
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_better += __shfl_xor(n_better, off, 64);
+    if (lane == 0 && n_better > 0) {
+        flags[cur * nb + b] = 1;                                          // exact: something changed
+        if ((xb & 15) == 0) atomicAdd(&counts[cur * nb + b], write_map ? n_better : -n_better);   // sampled: how much
+    }
 }
 
 // dist[b][v][s] -> out[(b*sb+s)][v], 64-node x sb-source tiles through LDS.
@@ -361,10 +426,12 @@ int choose_sb(int32_t n, int32_t n_sources) {
     return 64;
 }
 
-size_t chunk_bytes(int32_t n, int64_t nnz) {
+size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
+    const size_t words = ((size_t)n + 3) / 4;
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
-           geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1));
+           geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
+           geo::align_up(3 * (size_t)nb * 4);
 }
 
 size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
@@ -384,7 +451,7 @@ extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int64_t nnz, int32_t n_sou
         const size_t m = multi_bytes(nn, (ss + sb - 1) / sb, sb, true);
         multi = m > multi ? m : multi;
     }
-    multi += chunk_bytes(nn, nnz);
+    multi += chunk_bytes(nn, nnz, (ss + 15) / 16);
     size_t single = geo::align_up((size_t)nn * sizeof(double)) + 256;
     return (multi > single ? multi : single) + 1024;
 }
@@ -400,9 +467,9 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     const int32_t nb = (n_sources + sb - 1) / sb;
     const bool chunked = sb == 16 && n_sources > 16;       // 16-edge chunk work items (see sweep_chunk16_kernel)
     GEO_REQUIRE(nnz >= 0, "geo_sssp_multi: nnz must be given");
-    if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz) : 0)) {
+    if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz, nb) : 0)) {
         geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes,
-                       multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz) : 0));
+                       multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz, nb) : 0));
         return GEO_E_WORKSPACE;
     }
     geo::Arena ar(ws, ws_bytes);
@@ -419,8 +486,20 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     GEO_LAUNCH_CHECK();
 
     int32_t *chunk_node = nullptr, *chunk_start = nullptr;
+    uint32_t *bits = nullptr;
+    int32_t *counts = nullptr;
+    const int act_mode = getenv("GEO_SSSP_ACT") ? atoi(getenv("GEO_SSSP_ACT")) : 1;
+    const int32_t words = (n + 3) / 4;                       // activity map: one byte per node, in 4-byte words
     int64_t n_chunks = 0;
     if (chunked) {
+        bits = ar.take<uint32_t>(3 * (size_t)nb * words);
+        counts = ar.take<int32_t>(3 * (size_t)nb);
+        GEO_REQUIRE(bits != nullptr && counts != nullptr, "geo_sssp_multi: workspace carve failed");
+        GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * (size_t)nb * 4, stream));
+        GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb * words * 4, stream));
+        source_bits_kernel<<<geo::grid_for(n_sources, 256, 64), 256, 0, stream>>>(w.src_pad, n_sources, n, sb, words,
+                                                                                   bits + 2 * (size_t)nb * words);
+        GEO_LAUNCH_CHECK();
         int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
         const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
         chunk_node = ar.take<int32_t>(max_chunks);
@@ -462,14 +541,16 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, gs, w.dist, w.flags, \
                                                           prev, cur, next, sweeps == 0)
             if (chunked) {
+                uint32_t *bcur = bits + (size_t)cur * nb * words, *bprev = bits + (size_t)prev * nb * words;
+                if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb * words * 4, stream));
                 if (weights)
                     sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                          (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                         prev, cur, next, sweeps == 0);
+                                                                         counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode);
                 else
                     sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                           (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                          prev, cur, next, sweeps == 0);
+                                                                          counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode);
             } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
             else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
