@@ -133,27 +133,42 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
     it, it1 = 0, (K if absorb_last else K - 1)
     n_valid = K
-    # frontier sweeps enqueued per solve: the first solves cross the whole graph, later ones only the new
-    # centre's cell (pruned); a solve that needs more aborts harmlessly and is redone host-driven
-    sweeps, warm = 10, 16
-    status = np.zeros(2, dtype=np.int32)
+    # Solves: the first `warm` centres cross most of the graph -> multi-launch frontier sweeps; afterwards the
+    # pruned cells are small -> one-workgroup solves (LDS queues).  A solve that outgrows the queue, or needs
+    # more sweeps than were enqueued, aborts harmlessly and is redone another way.
+    sweeps, warm = int(os.environ.get("GEO_KPP_SWEEPS", "10")), 16
+    # one-workgroup solves only win for frontiers of a few dozen nodes (32 lane groups per workgroup); at the
+    # shipped sizes the cells hold hundreds to thousands of nodes, so this stays opt-in
+    use_micro = os.environ.get("GEO_KPP_MICRO", "0") == "1"
+    finite, redo_multi = False, False
+    status = np.zeros(4, dtype=np.int32)
     while it < it1:
-        seg_end = min(it1, warm) if it < warm else it1
+        if it < warm:
+            seg_end, micro, sw = min(it1, warm), 0, 2 * sweeps
+        elif redo_multi or not use_micro:
+            seg_end, micro, sw = (it + 1 if redo_multi else it1), 0, (2 * sweeps if redo_multi else sweeps)
+        else:
+            seg_end, micro, sw = it1, 1, sweeps
+        redo_multi = False
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
                                          ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
-                                         K, 2 * sweeps if it < warm else sweeps, ptr(ws), ws.numel(),
-                                         status.ctypes.data, stream_ptr()),
+                                         K, sw, micro, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
+                                         stream_ptr()),
                        "geo_kpp_chain")
         t, reason = int(status[0]), int(status[1])
+        finite = finite or int(status[2]) == 0          # inf entries only ever disappear from d_min
         if t < 0:
             chain.solves += seg_end - it
             it = seg_end
             continue
         chain.solves += t - it + 1
+        if reason == 4:                                  # cell too large for the one-workgroup queue: nothing applied
+            redo_multi, it = True, t
+            continue
         centers_h = centers_d[: t + 1].cpu().numpy().astype(int).tolist()
         if reason == 1:                                  # this solve needs more sweeps: host-driven solve
-            sweeps = min(2 * sweeps, 4096)
+            sweeps = min(2 * sweeps, 2048)
             chain.absorb(centers_h[t], t)
         if t + 1 >= K:
             break
