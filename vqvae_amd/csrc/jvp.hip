@@ -22,6 +22,7 @@
 #include "geo_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -32,6 +33,8 @@ constexpr int MAX_BLOCKS = 4;   // input pixels feeding one output pixel (2x2 in
 constexpr int BACK_TS = 8;      // samples per back-kernel workgroup
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 struct Shape {
     int d, c0, c1, c2, co, s_out, pad3, p_out;   // p_out = co * s_out * s_out
@@ -313,6 +316,263 @@ __global__ __launch_bounds__(256) void mid_kernel(const float *__restrict__ pre1
     }
 }
 
+// ---------------------------------------------------------------------------------- mid, bf16 x 3 split
+// The f32 MFMA runs at 1/16 of the bf16 rate.  Every f32 operand is split exactly into three bf16 parts
+// (a = a1 + a2 + a3, each part the truncated leading 8 mantissa bits of the remainder) and the product is
+// formed as a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 with f32 accumulation inside v_mfma_f32_32x32x16_bf16:
+// the dropped terms are below 2^-23 |a||b|, the level of one f32 rounding, for 6/16 of the matrix time.
+__device__ __forceinline__ void split3(float a, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
+    const unsigned b1 = __float_as_uint(a) & 0xffff0000u;
+    const float r1 = a - __uint_as_float(b1);                 // exact
+    const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b2);                // exact
+    p1 = (unsigned short)(b1 >> 16);
+    p2 = (unsigned short)(b2 >> 16);
+    p3 = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// B3[chunk][blk][part][ks][h][col][8] bf16: lane (col, h) of the 32x32x16 B operand reads 16 contiguous bytes
+__global__ __launch_bounds__(256) void pack_mid_bf16_kernel(const float *__restrict__ B2p, int c1, int n_chunks,
+                                                           unsigned short *__restrict__ B3) {
+    const size_t per_blk = (size_t)c1 * NC;
+    const size_t total = (size_t)n_chunks * MAX_BLOCKS * per_blk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % NC);
+        const int k = (int)((i / NC) % c1);
+        const size_t cb = i / per_blk;                        // chunk * MAX_BLOCKS + blk
+        unsigned short p[3];
+        split3(B2p[i], p[0], p[1], p[2]);
+        const int ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
+        for (int part = 0; part < 3; ++part)
+            B3[(((cb * 3 + part) * (c1 / 16) + ks) * 2 + h) * (size_t)NC * 8 + (size_t)col * 8 + j] = p[part];
+    }
+}
+
+template <int C1>
+__global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                                      const NormConst *__restrict__ consts1, int consts_per_group,
+                                                      int tiles_per_group, ChunkTable tab, int opix_per_chunk, int c2,
+                                                      const unsigned short *__restrict__ B3, const float *__restrict__ b2,
+                                                      float *__restrict__ pre2, float *__restrict__ tpre2,
+                                                      double *__restrict__ partial2, int want_stats,
+                                                      const int32_t *__restrict__ slot_valid) {
+    constexpr int LDK = C1 + 8;                               // bf16 elements per row (+16 B pad)
+    constexpr int KS = C1 / 16;                               // 16-deep MFMA steps per input pixel
+    __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];   // [part][primal|tangent][row][k]
+    __shared__ NormConst kc[C1];
+    const int tile = blockIdx.x, chunk = blockIdx.y;
+    const int group = tile / tiles_per_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n1 = 4 * C1, n2 = 16 * c2;
+    const size_t slot0 = (size_t)tile * TS;
+    for (int c = threadIdx.x; c < C1; c += 256) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
+
+    f32x16 accp, acct;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
+
+    const int nblk = tab.nblk[chunk];
+    const int r = lane & 31, h = lane >> 5;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int ip = tab.ipix[chunk][blk];
+        __syncthreads();
+        {   // stage A: thread -> (sample = tid/8, C1/8 consecutive channels); norm1 + ReLU, then the 3-way split
+            const int s = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * (C1 / 8);
+            const float *xp = pre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+            const float *xt = tpre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+#pragma unroll
+            for (int k = 0; k < C1 / 8; ++k) {
+                float a, ta;
+                norm_relu(kc[k0 + k], xp[k], xt[k], &a, &ta);
+                split3(a, A3[0][0][s][k0 + k], A3[1][0][s][k0 + k], A3[2][0][s][k0 + k]);
+                split3(ta, A3[0][1][s][k0 + k], A3[1][1][s][k0 + k], A3[2][1][s][k0 + k]);
+            }
+        }
+        // B fragments of this block, all three parts: lane (col r of the wave's 32, half h)
+        bf16x8 b[3][KS];
+        const unsigned short *bsrc = B3 + ((size_t)(chunk * MAX_BLOCKS + blk) * 3 * KS * 2) * (size_t)NC * 8;
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                b[part][ks] = *reinterpret_cast<const bf16x8 *>(
+                    bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wave * 32 + r) * 8);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 ap[3], at[3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
+                at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
+            }
+            // smallest terms first
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct, 0, 0, 0);
+        }
+    }
+
+    // epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]  (same map as the f32 MFMA)
+    const int col = wave * 32 + (lane & 31);
+    const int lo = col / c2, co = col % c2;
+    const bool col_ok = lo < opix_per_chunk;
+    const int op = col_ok ? tab.opix[chunk][lo] : 0;
+    const float bias = col_ok ? b2[co] : 0.f;
+    double sx = 0, sxx = 0, st_ = 0, sxt = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        const float x = accp[q] + bias, t = acct[q];
+        if (col_ok) {
+            pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
+            tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
+            if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
+        }
+    }
+    if (want_stats) {
+        sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+        st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+        if (lane < 32 && col_ok) {
+            double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
+            p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
+        }
+    }
+}
+
+// ---- all eight 128-column chunks of a tile in ONE workgroup (dec_channels[2] = 64) ----------------
+// Staging an input pixel's A block (norm1 + ReLU + 3-way split of 32 x C1 primal and tangent values) costs
+// about as much VALU time as the 96 bf16 MFMAs one chunk spends on it.  Here the block is staged once and
+// used by the five chunks that need it; the 8 x 2 accumulator tiles (256 registers) stay resident at one
+// wave per SIMD.
+template <int C1>
+__global__ __launch_bounds__(256, 1) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                                        const NormConst *__restrict__ consts1, int consts_per_group,
+                                                        int tiles_per_group, ChunkTable tab, int c2,
+                                                        const unsigned short *__restrict__ B3,
+                                                        const float *__restrict__ b2, float *__restrict__ pre2,
+                                                        float *__restrict__ tpre2, double *__restrict__ partial2,
+                                                        int want_stats, const int32_t *__restrict__ slot_valid) {
+    constexpr int LDK = C1 + 8;
+    constexpr int KS = C1 / 16;
+    constexpr int NCH = 8;
+    __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];
+    __shared__ NormConst kc[C1];
+    const int tile = blockIdx.x;
+    const int group = tile / tiles_per_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n1 = 4 * C1, n2 = 16 * c2;
+    const size_t slot0 = (size_t)tile * TS;
+    for (int c = threadIdx.x; c < C1; c += 256) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
+
+    f32x16 accp[NCH], acct[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accp[ch][i] = 0.f; acct[ch][i] = 0.f; }
+
+    const int r = lane & 31, h = lane >> 5;
+    for (int ip = 0; ip < 4; ++ip) {
+        __syncthreads();
+        {   // stage A once per input pixel: thread -> (sample = tid/8, 16 consecutive channels), 16-byte LDS stores
+            const int s = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * (C1 / 8);
+            const float *xp = pre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+            const float *xt = tpre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+#pragma unroll
+            for (int k8 = 0; k8 < C1 / 8; k8 += 8) {
+                u16x8 pp[3], pt[3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float a, ta;
+                    norm_relu(kc[k0 + k8 + k], xp[k8 + k], xt[k8 + k], &a, &ta);
+                    unsigned short q1, q2, q3;
+                    split3(a, q1, q2, q3);
+                    pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3;
+                    split3(ta, q1, q2, q3);
+                    pt[0][k] = q1; pt[1][k] = q2; pt[2][k] = q3;
+                }
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    *reinterpret_cast<u16x8 *>(&A3[part][0][s][k0 + k8]) = pp[part];
+                    *reinterpret_cast<u16x8 *>(&A3[part][1][s][k0 + k8]) = pt[part];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            int blk = -1;                                      // position of this input pixel in the chunk's block list
+#pragma unroll
+            for (int j = 0; j < MAX_BLOCKS; ++j)
+                if (j < tab.nblk[ch] && tab.ipix[ch][j] == ip) blk = j;
+            if (blk < 0) continue;                             // wave-uniform
+            bf16x8 b[3][KS];
+            const unsigned short *bsrc = B3 + ((size_t)(ch * MAX_BLOCKS + blk) * 3 * KS * 2) * (size_t)NC * 8;
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    b[part][ks] = *reinterpret_cast<const bf16x8 *>(
+                        bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wave * 32 + r) * 8);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 ap[3], at[3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
+                    at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
+                }
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct[ch], 0, 0, 0);
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct[ch], 0, 0, 0);
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct[ch], 0, 0, 0);
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct[ch], 0, 0, 0);
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct[ch], 0, 0, 0);
+                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[ch], 0, 0, 0);
+                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[ch], 0, 0, 0);
+            }
+        }
+    }
+
+    const int colw = wave * 32 + (lane & 31);
+    const int lo = colw / c2, co = colw % c2;
+    const float bias = b2[co];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int op = tab.opix[ch][lo];
+        double sx = 0, sxx = 0, st_ = 0, sxt = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float x = accp[ch][q] + bias, t = acct[ch][q];
+            pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
+            tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
+            if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
+        }
+        if (want_stats) {
+            sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+            st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+            if (lane < 32) {
+                double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
+                p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
                                                         int64_t n_slots, int32_t *__restrict__ slot_valid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
@@ -476,6 +736,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     size_t b = 0;
     b += geo::align_up((size_t)s.d * s.n1 * 4) + geo::align_up((size_t)s.n1 * 4);          // M01, b01
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
+    b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 2 * 3);               // B3 (bf16 x 3)
     b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
     b += geo::align_up(tiles * s.n1 * 4 * 8) + geo::align_up(tiles * s.n2 * 4 * 8);         // partial sums
@@ -512,6 +773,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     float *M01 = ar.take<float>((size_t)s.d * s.n1);
     float *b01 = ar.take<float>((size_t)s.n1);
     float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
+    unsigned short *B3 = ar.take<unsigned short>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 3);
     float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
     float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
     float *pre2 = ar.take<float>(slots * s.n2), *tpre2 = ar.take<float>(slots * s.n2);
@@ -531,6 +793,14 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     GEO_LAUNCH_CHECK();
     pack_back_kernel<<<geo::grid_for(16 * s.co * s.c2, 256), 256, 0, stream>>>(dc->w3, s.c2, s.co, W3p);
     GEO_LAUNCH_CHECK();
+    // ConvT2 on the matrix cores: bf16 x 3 split by default, exact-f32 MFMA with GEO_JVP_MID=f32
+    const char *mid_env = getenv("GEO_JVP_MID");
+    const bool mid_split = !(mid_env && mid_env[0] == 'f') && s.c1 % 16 == 0;
+    if (mid_split) {
+        pack_mid_bf16_kernel<<<geo::grid_for((int64_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC, 256), 256, 0, stream>>>(
+            B2p, s.c1, s.n_chunks, B3);
+        GEO_LAUNCH_CHECK();
+    }
 
     const bool batch_stats = dc->norm == 1 && dc->bn_train;
     if (!batch_stats) {
@@ -569,9 +839,30 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     mid_kernel<C1V><<<mgrid, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, tab,       \
                                                s.opix_per_chunk, s.c2, B2p, dc->b2, pre2, tpre2, part2,             \
                                                batch_stats ? 1 : 0, slot_valid)
-        if (s.c1 == 128) GEO_MID(128);
-        else if (s.c1 == 64) GEO_MID(64);
-        else GEO_MID(32);
+#define GEO_MID3(C1V)                                                                                              \
+    mid_bf16_kernel<C1V><<<mgrid, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, tab,  \
+                                                    s.opix_per_chunk, s.c2, B3, dc->b2, pre2, tpre2, part2,        \
+                                                    batch_stats ? 1 : 0, slot_valid)
+        const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && !(mid_env && mid_env[0] == 'c');
+        if (mid_all) {
+#define GEO_MIDA(C1V)                                                                                              \
+    mid_all_kernel<C1V><<<(unsigned)p_tiles, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,                \
+                                                               pl.tiles_per_group, tab, s.c2, B3, dc->b2, pre2,     \
+                                                               tpre2, part2, batch_stats ? 1 : 0, slot_valid)
+            if (s.c1 == 128) GEO_MIDA(128);
+            else if (s.c1 == 64) GEO_MIDA(64);
+            else GEO_MIDA(32);
+#undef GEO_MIDA
+        } else if (mid_split) {
+            if (s.c1 == 128) GEO_MID3(128);
+            else if (s.c1 == 64) GEO_MID3(64);
+            else GEO_MID3(32);
+        } else {
+            if (s.c1 == 128) GEO_MID(128);
+            else if (s.c1 == 64) GEO_MID(64);
+            else GEO_MID(32);
+        }
+#undef GEO_MID3
 #undef GEO_MID
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
