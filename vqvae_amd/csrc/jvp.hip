@@ -451,11 +451,13 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
 
 // ---- all eight 128-column chunks of a tile in ONE workgroup (dec_channels[2] = 64) ----------------
 // Staging an input pixel's A block (norm1 + ReLU + 3-way split of 32 x C1 primal and tangent values) costs
-// about as much VALU time as the 96 bf16 MFMAs one chunk spends on it.  Here the block is staged once and
-// used by the five chunks that need it; the 8 x 2 accumulator tiles (256 registers) stay resident at one
-// wave per SIMD.
+// about as much VALU time as the 96 bf16 MFMAs one chunk spends on it.  Here the block is staged once (by
+// 512 threads) and used by the five chunks that need it.  Waves 0-3 own chunks {0,3,4,7}, waves 4-7 chunks
+// {1,2,5,6} (10 of the 20 (pixel, chunk) products each, 2 or 3 per pixel): 4 x 2 accumulator tiles = 128
+// registers per wave, so two waves share a SIMD and one's weight-fragment loads (L2) hide behind the other's
+// MFMAs.
 template <int C1>
-__global__ __launch_bounds__(256, 1) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+__global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
                                                         const NormConst *__restrict__ consts1, int consts_per_group,
                                                         int tiles_per_group, ChunkTable tab, int c2,
                                                         const unsigned short *__restrict__ B3,
@@ -464,52 +466,64 @@ __global__ __launch_bounds__(256, 1) void mid_all_kernel(const float *__restrict
                                                         int want_stats, const int32_t *__restrict__ slot_valid) {
     constexpr int LDK = C1 + 8;
     constexpr int KS = C1 / 16;
-    constexpr int NCH = 8;
-    __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];
+    constexpr int NL = 4;                                      // chunks per wave group
+    constexpr int CPT = C1 / 16;                               // channels staged per thread
+    __shared__ __attribute__((aligned(16))) unsigned short A3[2][3][2][TS][LDK];   // double buffered over input pixels
     __shared__ NormConst kc[C1];
     const int tile = blockIdx.x;
     const int group = tile / tiles_per_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wq = wave & 3, wg = wave >> 2;                   // column quarter, chunk group
     const int n1 = 4 * C1, n2 = 16 * c2;
     const size_t slot0 = (size_t)tile * TS;
-    for (int c = threadIdx.x; c < C1; c += 256) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
+    for (int c = threadIdx.x; c < C1; c += 512) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
 
-    f32x16 accp[NCH], acct[NCH];
+    f32x16 accp[NL], acct[NL];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int lc = 0; lc < NL; ++lc)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { accp[ch][i] = 0.f; acct[ch][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { accp[lc][i] = 0.f; acct[lc][i] = 0.f; }
 
     const int r = lane & 31, h = lane >> 5;
+    // staging: thread -> (sample = tid/16, CPT consecutive channels).  The raw pre-activations of the NEXT input
+    // pixel are fetched (HBM) while the MFMAs of the current one run; one barrier per pixel.
+    const int ss = threadIdx.x >> 4, k0 = (threadIdx.x & 15) * CPT;
+    float rawp[CPT], rawt[CPT];
+    {
+        const float *xp = pre1 + (slot0 + ss) * n1 + k0, *xt = tpre1 + (slot0 + ss) * n1 + k0;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
+    }
+    __syncthreads();                                           // kc visible
     for (int ip = 0; ip < 4; ++ip) {
-        __syncthreads();
-        {   // stage A once per input pixel: thread -> (sample = tid/8, 16 consecutive channels), 16-byte LDS stores
-            const int s = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * (C1 / 8);
-            const float *xp = pre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
-            const float *xt = tpre1 + (slot0 + s) * n1 + (size_t)ip * C1 + k0;
+        const int buf = ip & 1;
+        {
+            unsigned short pp[3][CPT], pt[3][CPT];
 #pragma unroll
-            for (int k8 = 0; k8 < C1 / 8; k8 += 8) {
-                u16x8 pp[3], pt[3];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float a, ta;
-                    norm_relu(kc[k0 + k8 + k], xp[k8 + k], xt[k8 + k], &a, &ta);
-                    unsigned short q1, q2, q3;
-                    split3(a, q1, q2, q3);
-                    pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3;
-                    split3(ta, q1, q2, q3);
-                    pt[0][k] = q1; pt[1][k] = q2; pt[2][k] = q3;
-                }
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    *reinterpret_cast<u16x8 *>(&A3[part][0][s][k0 + k8]) = pp[part];
-                    *reinterpret_cast<u16x8 *>(&A3[part][1][s][k0 + k8]) = pt[part];
-                }
+            for (int k = 0; k < CPT; ++k) {
+                float a, ta;
+                norm_relu(kc[k0 + k], rawp[k], rawt[k], &a, &ta);
+                split3(a, pp[0][k], pp[1][k], pp[2][k]);
+                split3(ta, pt[0][k], pt[1][k], pt[2][k]);
             }
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    A3[buf][part][0][ss][k0 + k] = pp[part][k];
+                    A3[buf][part][1][ss][k0 + k] = pt[part][k];
+                }
+        }
+        if (ip < 3) {
+            const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
+            const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
         }
         __syncthreads();
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
+        for (int lc = 0; lc < NL; ++lc) {
+            const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
             int blk = -1;                                      // position of this input pixel in the chunk's block list
 #pragma unroll
             for (int j = 0; j < MAX_BLOCKS; ++j)
@@ -522,42 +536,43 @@ __global__ __launch_bounds__(256, 1) void mid_all_kernel(const float *__restrict
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     b[part][ks] = *reinterpret_cast<const bf16x8 *>(
-                        bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wave * 32 + r) * 8);
+                        bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wq * 32 + r) * 8);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 ap[3], at[3];
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
-                    at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
+                    ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][0][r][ks * 16 + h * 8]);
+                    at[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][1][r][ks * 16 + h * 8]);
                 }
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct[ch], 0, 0, 0);
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct[ch], 0, 0, 0);
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct[ch], 0, 0, 0);
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct[ch], 0, 0, 0);
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct[ch], 0, 0, 0);
-                accp[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[ch], 0, 0, 0);
-                acct[ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[ch], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct[lc], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct[lc], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct[lc], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct[lc], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct[lc], 0, 0, 0);
+                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[lc], 0, 0, 0);
+                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[lc], 0, 0, 0);
             }
         }
     }
 
-    const int colw = wave * 32 + (lane & 31);
+    const int colw = wq * 32 + (lane & 31);
     const int lo = colw / c2, co = colw % c2;
     const float bias = b2[co];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int lc = 0; lc < NL; ++lc) {
+        const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
         const int op = tab.opix[ch][lo];
         double sx = 0, sxx = 0, st_ = 0, sxt = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float x = accp[ch][q] + bias, t = acct[ch][q];
+            const float x = accp[lc][q] + bias, t = acct[lc][q];
             pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
             tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
             if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
@@ -843,10 +858,11 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     mid_bf16_kernel<C1V><<<mgrid, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, tab,  \
                                                     s.opix_per_chunk, s.c2, B3, dc->b2, pre2, tpre2, part2,        \
                                                     batch_stats ? 1 : 0, slot_valid)
-        const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && !(mid_env && mid_env[0] == 'c');
+        const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
+                             !(mid_env && mid_env[0] == 'c');
         if (mid_all) {
 #define GEO_MIDA(C1V)                                                                                              \
-    mid_all_kernel<C1V><<<(unsigned)p_tiles, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,                \
+    mid_all_kernel<C1V><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,                \
                                                                pl.tiles_per_group, tab, s.c2, B3, dc->b2, pre2,     \
                                                                tpre2, part2, batch_stats ? 1 : 0, slot_valid)
             if (s.c1 == 128) GEO_MIDA(128);
