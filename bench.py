@@ -81,13 +81,15 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
             return (torch.full((G.n,), float("inf"), device=z.device), torch.zeros(G.n, dtype=torch.int32, device=z.device))
         _, _, dmin_, arg_, _ = sssp_multi_device(G, src[s0:s1].contiguous(), want_D=False, want_min=True)
         ms_, launches_ = np.zeros(1, np.float64), np.zeros(1, np.int32)
-        _lib.load().geo_sssp_last_profile(ms_.ctypes.data, launches_.ctypes.data)
+        layout = _lib.load().geo_sssp_last_profile(ms_.ctypes.data, launches_.ctypes.data)
         prof["ms"], prof["launches"], prof["sources"] = float(ms_[0]), int(launches_[0]), s1 - s0
+        prof["kernel"] = "sweep_chunk16_kernel" if layout >= 1000 else f"sweep_multi_kernel<{layout}>"
         return dmin_, arg_
 
     dmin, arg = sharded_assign(len(res["medoids"]), solve)
     ms, launches = np.array([prof.get("ms", 0.0)]), np.array([prof.get("launches", 0)])
     res["sources_this_rank"] = prof.get("sources", 0)
+    res["sweep_kernel"] = prof.get("kernel", "sweep_multi_kernel")
     torch.cuda.synchronize(z.device)
     timers["assign_sweep"] = timers.get("assign_sweep", 0.0) + time.perf_counter() - t0
     res["assign_batched"] = arg
@@ -150,7 +152,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GEO_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -183,11 +189,13 @@ def main():
     sweep_ms, launches = prof
     algo_bytes = res["sources_this_rank"] * (16.0 * nnz + 16.0 * n)    # B_sssp x sources solved on this rank
     achieved = algo_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    traffic = None
+    traffic = None                                      # PMC-derived bytes per launch: measured for c2 on one GPU only
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.workload == "c2" and world == 1:
         with open(tpath) as f:
-            traffic = json.load(f).get("sweep_multi_hbm_bytes_per_launch")
+            tj = json.load(f)
+        if tj.get("kernel") == res["sweep_kernel"]:
+            traffic = tj.get("hbm_bytes_per_launch")
     ms_per_step = elapsed / args.steps * 1e3
     out = {
         "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] / (elapsed / args.steps),
@@ -201,7 +209,7 @@ def main():
                                    f"k++ chain replicated") if world > 1 else "1 gpu"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "sweep_multi_kernel", "launches_per_step": launches,
+                     "kernel": res["sweep_kernel"], "launches_per_step": launches,
                      "avg_launch_ms": sweep_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, launches)},
         "stages_ms": {k_: v * 1e3 / args.steps for k_, v in timers.items()},

@@ -60,7 +60,8 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
                    void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 
 /* Device time (ms, HIP events on the call's stream) spent in the relaxation sweeps of the last
- * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline. */
+ * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
+ * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel. */
 int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
 
 /* One source; fused k-means++ bookkeeping of kmeans_optimized.py:43-44 and the single-pass

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void finish_single_kernel(const double *__rest
 // device time of the relaxation sweeps of the last geo_sssp_multi call (HIP events on its stream)
 double g_last_sweep_ms = 0.0;
 int32_t g_last_sweep_launches = 0;
+int32_t g_last_layout = 0;             // sources per batch of the last geo_sssp_multi call, +1000 when chunked
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 struct MultiWs {
@@ -573,6 +574,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     }
     if (sweeps_out) *sweeps_out = sweeps;
     g_last_sweep_launches = sweeps;
+    g_last_layout = sb + (chunked ? 1000 : 0);
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {
@@ -601,7 +603,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
 extern "C" int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches) {
     if (sweep_ms) *sweep_ms = g_last_sweep_ms;
     if (sweep_launches) *sweep_launches = g_last_sweep_launches;
-    return GEO_OK;
+    return g_last_layout;       // >= 0: sources per batch (+1000: 16-edge chunk work items), never an error
 }
 
 extern "C" int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
