@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void kpp_fill_inf_kernel(double *__restrict__ 
 // r[0..7] of one <=128-element leaf; they are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
 // `exact_max`: the per-block maxima of kpp_max_kernel are reduced here (needed when d_min still holds inf
 // entries, which are replaced by 2*max_finite); otherwise every entry is finite and no maximum is needed.
-__global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, const float *__restrict__ dmin,
+// `fuse_finish`: the d_min / argmin update of the solve just finished (and the reset of its distances) is done
+// here, element by element, instead of by kpp_finish_kernel -- every node is visited exactly once by the leaves.
+__global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, float *__restrict__ dmin,
+                                                      int32_t *__restrict__ argmin, double *__restrict__ d,
+                                                      int fuse_finish, int last_next, int32_t pos,
                                                       const uint8_t *__restrict__ is_center,
                                                       const float *__restrict__ part_max,
                                                       const int32_t *__restrict__ part_inf, int n_part, int exact_max,
@@ -266,6 +270,10 @@ __global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, const float 
                                                       const int32_t *__restrict__ leaf_len, int n_leaves,
                                                       float *__restrict__ val) {
     if (ctl->abort_iter >= 0) return;
+    if (fuse_finish && ctl->fcount[last_next] != 0) {          // the solve did not converge: apply nothing
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
+        return;
+    }
     __shared__ float smax;
     __shared__ int32_t sinf;
     float maxf = 0.0f;
@@ -295,7 +303,15 @@ __global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, const float 
     const int len = live ? leaf_len[leaf] : 0;
     const int m8 = len - (len % 8);
     auto prob_at = [&](int32_t i) {
-        const float x = dmin[i];
+        float x = dmin[i];
+        if (fuse_finish) {
+            const double dd = d[i];
+            if (dd < inf64()) {                            // touched by the solve of centre `pos`
+                const float xd = (float)dd;
+                if (xd < x) { x = xd; dmin[i] = xd; argmin[i] = pos; }
+                d[i] = inf64();
+            }
+        }
         const float safe = any_finite ? (x < inf32() ? x : sub) : 1.0f;
         const float p = is_center[i] ? 0.0f : safe * safe;
         probs[i] = p;
@@ -601,10 +617,13 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
                 last_next = next;
             }
         }
-        kpp_finish_kernel<<<geo::grid_for(n, 256, 256), 256, 0, s>>>(w.ctl, w.d, dmin, argmin, w.touched, last_next, t);
+        const int fuse = (!exact_max && t + 1 < n_centers_total) ? 1 : 0;
+        if (!fuse)
+            kpp_finish_kernel<<<geo::grid_for(n, 256, 256), 256, 0, s>>>(w.ctl, w.d, dmin, argmin, w.touched, last_next, t);
         if (t + 1 < n_centers_total) {
             if (exact_max) kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max, w.part_inf);
-            kpp_leaf_kernel<<<(dp.n_leaves * 8 + 255) / 256, 256, 0, s>>>(w.ctl, dmin, is_center, w.part_max, w.part_inf,
+            kpp_leaf_kernel<<<(dp.n_leaves * 8 + 255) / 256, 256, 0, s>>>(w.ctl, dmin, argmin, w.d, fuse, last_next, t,
+                                                                          is_center, w.part_max, w.part_inf,
                                                                           FINISH_GRID, exact_max, w.probs, dp.leaf_start,
                                                                           dp.leaf_len, dp.n_leaves, dp.val);
             kpp_tree_kernel<<<1, 1024, 0, s>>>(w.ctl, dp.n_leaves, dp.node_l, dp.node_r, dp.level_off, dp.n_levels,

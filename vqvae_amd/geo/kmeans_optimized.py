@@ -136,7 +136,7 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     # Solves: the first `warm` centres cross most of the graph -> multi-launch frontier sweeps; afterwards the
     # pruned cells are small -> one-workgroup solves (LDS queues).  A solve that outgrows the queue, or needs
     # more sweeps than were enqueued, aborts harmlessly and is redone another way.
-    sweeps, warm = int(os.environ.get("GEO_KPP_SWEEPS", "10")), 16
+    sweeps, warm = int(os.environ.get("GEO_KPP_SWEEPS", "7")), 16
     # one-workgroup solves only win for frontiers of a few dozen nodes (32 lane groups per workgroup); at the
     # shipped sizes the cells hold hundreds to thousands of nodes, so this stays opt-in
     use_micro = os.environ.get("GEO_KPP_MICRO", "0") == "1"
