@@ -681,6 +681,150 @@ __global__ __launch_bounds__(256) void back_kernel(const float *__restrict__ pre
     }
 }
 
+// ---------------------------------------------------------------------------------- back on the matrix cores
+// ConvT3 as a [32 samples x 1024] x [1024 x P] product (P = 16 or 192 outputs, padded to 32-column tiles; taps that
+// fall outside the 4x4 kernel are zeros in the packed weights), same exact bf16 x 3 split as the mid kernel.
+// The 1024-deep reduction is cut into 8 blocks of 128 (two input pixels); inside a block the four waves take two
+// 16-deep steps each, and their partial tiles are summed through LDS before sigmoid' and the squared norm.
+// W3b[kb 8][part 3][ks 8][h 2][NP][8] bf16
+__global__ __launch_bounds__(256) void pack_back_bf16_kernel(const float *__restrict__ w3, int c2, int co_n, int s_out,
+                                                            int pad3, int np, unsigned short *__restrict__ W3b) {
+    const int K = 16 * c2, P = co_n * s_out * s_out;
+    const size_t total = (size_t)K * np;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % np), k = (int)(i / np);
+        float v = 0.f;
+        if (o < P) {
+            const int ip = k / c2, ci = k % c2, iy = ip >> 2, ix = ip & 3;
+            const int co = o / (s_out * s_out), oy = (o / s_out) % s_out, ox = o % s_out;
+            const int ky = oy + pad3 - 2 * iy, kx = ox + pad3 - 2 * ix;
+            if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = w3[(((size_t)ci * co_n + co) * 4 + ky) * 4 + kx];
+        }
+        unsigned short q[3];
+        split3(v, q[0], q[1], q[2]);
+        const int kb = k >> 7, kk = k & 127, ks = kk >> 4, h = (kk >> 3) & 1, j = kk & 7;
+        for (int part = 0; part < 3; ++part)
+            W3b[((((size_t)kb * 3 + part) * 8 + ks) * 2 + h) * (size_t)np * 8 + (size_t)o * 8 + j] = q[part];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
+                                                       const NormConst *__restrict__ consts2, int consts_per_group,
+                                                       int tiles_per_group, int co_n, int s_out,
+                                                       const unsigned short *__restrict__ W3b,
+                                                       const float *__restrict__ b3, float *__restrict__ norms) {
+    constexpr int C2 = 64, KB = 128, LDK = KB + 8, NP = NT * 32;
+    __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];     // 52 KB, reused for the reduction
+    __shared__ NormConst kc[C2];
+    const int tile = blockIdx.x;
+    const int group = tile / tiles_per_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n2 = 16 * C2, P = co_n * s_out * s_out;
+    const size_t slot0 = (size_t)tile * TS;
+    for (int c = threadIdx.x; c < C2; c += 256) kc[c] = consts2[(size_t)(consts_per_group ? group : 0) * C2 + c];
+
+    f32x16 accp[NT], acct[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accp[nt][i] = 0.f; acct[nt][i] = 0.f; }
+
+    const int r = lane & 31, h = lane >> 5;
+    const int ss = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 16;
+    for (int kb = 0; kb < 8; ++kb) {
+        __syncthreads();
+        {
+            const float *xp = pre2 + (slot0 + ss) * n2 + (size_t)kb * KB + k0;
+            const float *xt = tpre2 + (slot0 + ss) * n2 + (size_t)kb * KB + k0;
+#pragma unroll
+            for (int k8 = 0; k8 < 16; k8 += 8) {
+                u16x8 pp[3], pt[3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float a, ta;
+                    norm_relu(kc[(k0 + k8 + k) & (C2 - 1)], xp[k8 + k], xt[k8 + k], &a, &ta);
+                    unsigned short q1, q2, q3;
+                    split3(a, q1, q2, q3);
+                    pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3;
+                    split3(ta, q1, q2, q3);
+                    pt[0][k] = q1; pt[1][k] = q2; pt[2][k] = q3;
+                }
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    *reinterpret_cast<u16x8 *>(&A3[part][0][ss][k0 + k8]) = pp[part];
+                    *reinterpret_cast<u16x8 *>(&A3[part][1][ss][k0 + k8]) = pt[part];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int ks = wave * 2 + kq;                     // this wave's 16-deep steps of the block
+            bf16x8 ap[3], at[3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
+                at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+                    b[part] = *reinterpret_cast<const bf16x8 *>(
+                        W3b + ((((size_t)kb * 3 + part) * 8 + ks) * 2 + h) * (size_t)NP * 8 + (size_t)(nt * 32 + r) * 8);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0], acct[nt], 0, 0, 0);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2], acct[nt], 0, 0, 0);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1], acct[nt], 0, 0, 0);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0], acct[nt], 0, 0, 0);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1], acct[nt], 0, 0, 0);
+                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0], accp[nt], 0, 0, 0);
+                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0], acct[nt], 0, 0, 0);
+            }
+        }
+    }
+    // sum the four waves' partial tiles through LDS (one 32-column tile at a time), then sigmoid' and the norm
+    float *red = reinterpret_cast<float *>(&A3[0][0][0][0]);     // [wave 4][p|t 2][32 rows][33]
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    double sumsq = 0.0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rr = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            red[((wave * 2 + 0) * 32 + rr) * 33 + (lane & 31)] = accp[nt][q];
+            red[((wave * 2 + 1) * 32 + rr) * 33 + (lane & 31)] = acct[nt][q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int o = nt * 32 + c4 + c;
+            if (o < P) {
+                float x = b3[o / (s_out * s_out)], t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    x += red[((w * 2 + 0) * 32 + row) * 33 + c4 + c];
+                    t += red[((w * 2 + 1) * 32 + row) * 33 + c4 + c];
+                }
+                const float sg = 1.0f / (1.0f + expf(-x));
+                const float j = t * sg * (1.0f - sg);
+                sumsq += (double)(j * j);
+            }
+        }
+    }
+    sumsq += __shfl_xor(sumsq, 1, 64);
+    sumsq += __shfl_xor(sumsq, 2, 64);
+    sumsq += __shfl_xor(sumsq, 4, 64);
+    if ((threadIdx.x & 7) == 0) norms[slot0 + row] = (float)sqrt(sumsq);
+}
+
 __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ norms, int64_t e_base, int64_t e_count,
                                                      int batch, int slots_per_group, float *__restrict__ len_out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e_count; i += (int64_t)gridDim.x * blockDim.x) {
@@ -753,6 +897,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 2 * 3);               // B3 (bf16 x 3)
     b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
+    b += geo::align_up((size_t)16 * s.c2 * 192 * 3 * 2);                                    // W3b (bf16 x 3)
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
     b += geo::align_up(tiles * s.n1 * 4 * 8) + geo::align_up(tiles * s.n2 * 4 * 8);         // partial sums
     b += geo::align_up((groups + 1) * s.c1 * sizeof(NormConst)) + geo::align_up((groups + 1) * s.c2 * sizeof(NormConst));
@@ -790,6 +935,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
     unsigned short *B3 = ar.take<unsigned short>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 3);
     float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
+    unsigned short *W3b = ar.take<unsigned short>((size_t)16 * s.c2 * 192 * 3);
     float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
     float *pre2 = ar.take<float>(slots * s.n2), *tpre2 = ar.take<float>(slots * s.n2);
     double *part1 = ar.take<double>(tiles * s.n1 * 4), *part2 = ar.take<double>(tiles * s.n2 * 4);
@@ -811,6 +957,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     // ConvT2 on the matrix cores: bf16 x 3 split by default, exact-f32 MFMA with GEO_JVP_MID=f32
     const char *mid_env = getenv("GEO_JVP_MID");
     const bool mid_split = !(mid_env && mid_env[0] == 'f') && s.c1 % 16 == 0;
+    const int back_nt = (s.p_out + 31) / 32;
+    const bool back_mfma = mid_split && s.c2 == 64 && (back_nt == 1 || back_nt == 6) && !getenv("GEO_JVP_BACK_VALU");
+    if (back_mfma) {
+        pack_back_bf16_kernel<<<geo::grid_for((int64_t)16 * s.c2 * back_nt * 32, 256), 256, 0, stream>>>(
+            dc->w3, s.c2, s.co, s.s_out, s.pad3, back_nt * 32, W3b);
+        GEO_LAUNCH_CHECK();
+    }
     if (mid_split) {
         pack_mid_bf16_kernel<<<geo::grid_for((int64_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC, 256), 256, 0, stream>>>(
             B2p, s.c1, s.n_chunks, B3);
@@ -886,8 +1039,15 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                 part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups);
             GEO_LAUNCH_CHECK();
         }
-        back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
-            pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);
+        if (back_mfma && back_nt == 1)
+            back_mfma_kernel<1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
+                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms);
+        else if (back_mfma)
+            back_mfma_kernel<6><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
+                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms);
+        else
+            back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
+                pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);
         GEO_LAUNCH_CHECK();
         combine_kernel<<<geo::grid_for(e_count, 256), 256, 0, stream>>>(norms, e_base, e_count, batch,
                                                                         pl.slots_per_group, len_out);
