@@ -79,21 +79,20 @@ int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const 
  * (float32 D^2 weights, float32 add.reduce, fp64 cdf, searchsorted) from the uniform deviate u_host[t]
  * the caller took from the same RandomState stream.  centers i32 [n_centers_total] (centers[it0] set by
  * the caller), is_center u8 [n] (set for centers[0..it0]), dmin f32 [n] / argmin i32 [n] carried state.
- * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged); micro != 0
- * runs each solve inside one workgroup instead (LDS frontier queues; for the small pruned cells after the
- * first centres).  assume_finite != 0 promises that d_min has no inf entry left (status_out[2] of an earlier
- * call): the per-iteration maximum pass is skipped.
+ * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged).
+ * assume_finite != 0 promises that d_min has no inf entry left (status_out[2] of an earlier call): the
+ * per-iteration maximum pass is skipped.
  * status_out [host, 3 ints]: {abort_iter or -1, reason, inf entries of d_min at the last maximum pass}:
- * reason 1 = solve not converged, 4 = frontier outgrew the one-workgroup queue (for 1 and 4 nothing of that
- * iteration is applied), 2 = u too close to a cdf boundary, 3 = degenerate weights (for 2 and 3 the solve of
- * that iteration IS applied, the draw is not).  The caller repeats that step another way and resumes.
+ * reason 1 = solve not converged (nothing of that iteration is applied), 2 = u too close to a cdf boundary,
+ * 3 = degenerate weights (for 2 and 3 the solve of that iteration IS applied, the draw is not).  The caller
+ * repeats that step another way and resumes.
  * One synchronisation at the end.
  * ------------------------------------------------------------------------------------------ */
 size_t geo_kpp_workspace_bytes(int32_t n);
 int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
                   int32_t *centers, uint8_t *is_center, float *dmin, int32_t *argmin, const double *u_host,
                   int32_t it0, int32_t it1, int32_t n_centers_total, int32_t sweeps_per_solve,
-                  int32_t micro, int32_t assume_finite,
+                  int32_t assume_finite,
                   void *ws, size_t ws_bytes, int32_t *status_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -35,13 +35,11 @@ constexpr int FINISH_GRID = 256;
 
 struct KppCtl {
     int32_t abort_iter, abort_reason;      // -1 / 0 while healthy; reason 1 solve, 2 margin, 3 degenerate
-    int32_t n_touched;                     // nodes whose distance was lowered by the current solve
-    int32_t found, pick_idx, pick_ok;
     int32_t fcount[3];                     // frontier sizes, ring over sweeps
+    int32_t ticket[2];                     // "last block finishes the job" counters of the sum / draw kernels
     float total;
     float maxf;                            // max finite d_min (-1: none), basis of the pruning margin
     int32_t n_inf;                         // unreachable (inf) entries of d_min at the last max pass
-    double s_last;
 };
 
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
@@ -55,156 +53,85 @@ __device__ __forceinline__ float inf32() { return __int_as_float(0x7f800000); }
 // rounding of the quantities involved, all of which are < 2*max_finite), so no update is lost, and
 // nodes that ARE updated have an all-unpruned optimal path, hence their exact fixed-point distance.
 // Work per solve drops from O(nnz) per sweep to the size of the new centre's cell.
-// single stamp per node: solve_base = stamp_solve * 8192; within a solve, sweep sw uses base = solve_base + 2*sw
-// for "distance lowered" and base + 1 for "queued for the next sweep"
-__device__ __forceinline__ void kpp_begin(KppCtl *ctl, const int32_t *centers, int32_t pos, double *d, int32_t *mark,
-                                          int32_t *touched, int32_t *front0, int32_t stamp_solve) {
+// One stamp per node says "already queued for the sweep after sweep sw of solve s": s * 4096 + sw + 1.
+__device__ __forceinline__ void kpp_begin(KppCtl *ctl, const int32_t *centers, int32_t pos, double *d, int32_t *front0) {
     const int32_t src = centers[pos];
     d[src] = 0.0;
-    mark[src] = stamp_solve * 8192;
-    touched[0] = src;
     front0[0] = src;
-    ctl->n_touched = 1;
     ctl->fcount[0] = 1;
     ctl->fcount[1] = 0;
     ctl->fcount[2] = 0;
 }
 
 __global__ void kpp_begin_kernel(KppCtl *ctl, const int32_t *__restrict__ centers, int32_t pos, double *d,
-                                 int32_t *mark, int32_t *touched, int32_t *front0, int32_t stamp_solve) {
+                                 int32_t *front0) {
     if (ctl->abort_iter >= 0 || threadIdx.x != 0 || blockIdx.x != 0) return;
-    kpp_begin(ctl, centers, pos, d, mark, touched, front0, stamp_solve);
+    kpp_begin(ctl, centers, pos, d, front0);
 }
 
-// Expand one frontier node u (32 lanes share its adjacency row).  `du` must be a fresh (L2) read.
-template <bool WEIGHTED, typename AppendTouched, typename AppendFront>
-__device__ __forceinline__ void kpp_expand(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                           const float *__restrict__ weights, unsigned long long *dbits,
-                                           const float *__restrict__ dmin, int32_t *mark, int32_t u, double du, double tau,
-                                           int sub, int32_t solve_base, int32_t base, AppendTouched add_touched,
-                                           AppendFront add_front) {
-    const int32_t e0 = indptr[u], e1 = indptr[u + 1];
-    for (int32_t e = e0 + sub; e < e1; e += 32) {
-        const int32_t v = indices[e];
-        const double cand = du + (WEIGHTED ? (double)weights[e] : 1.0);
-        const unsigned long long cb = (unsigned long long)__double_as_longlong(cand);
-        if (cb >= dbits[v]) continue;                   // cheap pre-test (monotone: values only decrease)
-        const unsigned long long old = atomicMin(&dbits[v], cb);
-        if (cb < old) {
-            const bool open = cand <= (double)dmin[v] + tau;          // not pruned: goes to the next frontier
-            const int32_t before = atomicMax(&mark[v], open ? base + 1 : base);
-            if (before < solve_base) add_touched(v);                  // first time lowered in this solve
-            if (open && before < base + 1) add_front(v);              // first time queued in this sweep
-        }
-    }
-}
-
+// One sweep: every queued node u (32 lanes share its adjacency row; `d[u]` was written before this launch)
+// lowers its neighbours with a 64-bit atomicMin on the bit pattern; lowered, unpruned neighbours are queued
+// once for the next sweep.  The queue tail is advanced once per wave (ballot), not once per node.
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
                                                       const float *__restrict__ weights, double *d,
                                                       const float *__restrict__ dmin, int32_t *mark,
-                                                      int32_t *touched, const int32_t *__restrict__ fin,
-                                                      int32_t *__restrict__ fout, int cur, int next, int clear,
-                                                      int32_t stamp_solve, int32_t sw) {
+                                                      const int32_t *__restrict__ fin, int32_t *__restrict__ fout,
+                                                      int cur, int next, int clear, int32_t stamp_solve, int32_t sw) {
     if (ctl->abort_iter >= 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
     const int32_t cnt = ctl->fcount[cur];
     if (cnt == 0) return;
     const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
-    const int sub = threadIdx.x & 31;                       // 32 lanes share one frontier node (mean degree ~31)
+    const int sub = threadIdx.x & 31, lane = threadIdx.x & 63;       // 32 lanes per frontier node (mean degree ~31)
     const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int ngrp = (gridDim.x * blockDim.x) >> 5;
-    const int32_t solve_base = stamp_solve * 8192, base = solve_base + 2 * sw;
+    const int32_t stamp = stamp_solve * 4096 + sw + 1;
     unsigned long long *dbits = reinterpret_cast<unsigned long long *>(d);
     for (int32_t i = grp; i < cnt; i += ngrp) {
         const int32_t u = fin[i];
-        const double du = d[u];                             // fresh: written before this launch
+        const double du = d[u];
         if (du > (double)dmin[u] + tau) continue;           // pruned: cannot improve anything behind it
-        kpp_expand<WEIGHTED>(indptr, indices, weights, dbits, dmin, mark, u, du, tau, sub, solve_base, base,
-                             [&](int32_t v) { touched[atomicAdd(&ctl->n_touched, 1)] = v; },
-                             [&](int32_t v) { fout[atomicAdd(&ctl->fcount[next], 1)] = v; });
-    }
-}
-
-// The same solve inside ONE workgroup: frontier queues in LDS, sweeps separated by __syncthreads instead of
-// kernel launches.  Used once the cells are small (after the warm-up centres); a frontier that outgrows the
-// queue aborts the iteration (reason 4), which the caller redoes with the multi-launch sweeps above.
-constexpr int MICRO_QCAP = 8192;
-template <bool WEIGHTED>
-__global__ __launch_bounds__(1024) void kpp_micro_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
-                                                        const int32_t *__restrict__ indices,
-                                                        const float *__restrict__ weights, double *d,
-                                                        const float *__restrict__ dmin, int32_t *mark,
-                                                        int32_t *touched, const int32_t *__restrict__ centers,
-                                                        int32_t pos, int32_t stamp_solve, int32_t max_sweeps) {
-    if (ctl->abort_iter >= 0) return;
-    __shared__ int32_t q[2][MICRO_QCAP];
-    __shared__ int32_t qcnt[2], n_touched, overflow;
-    const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
-    const int sub = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = blockDim.x >> 5;
-    const int32_t solve_base = stamp_solve * 8192;
-    unsigned long long *dbits = reinterpret_cast<unsigned long long *>(d);
-    if (threadIdx.x == 0) {
-        const int32_t src = centers[pos];
-        d[src] = 0.0;
-        mark[src] = solve_base;
-        touched[0] = src;
-        q[0][0] = src;
-        qcnt[0] = 1; qcnt[1] = 0; n_touched = 1; overflow = 0;
-    }
-    __syncthreads();
-    int sw = 0;
-    for (; sw < max_sweeps; ++sw) {
-        const int cur = sw & 1, nxt = cur ^ 1;
-        const int32_t cnt = qcnt[cur];
-        if (cnt == 0 || overflow) break;
-        const int32_t base = solve_base + 2 * sw;
-        for (int32_t i = grp; i < cnt; i += ngrp) {
-            const int32_t u = q[cur][i];
-            // L2 read: another wave of this workgroup may have lowered d[u] during the previous sweep and this
-            // CU's L1 is not refreshed inside a kernel
-            const double du = __longlong_as_double((long long)__hip_atomic_load(&dbits[u], __ATOMIC_RELAXED,
-                                                                               __HIP_MEMORY_SCOPE_AGENT));
-            if (du > (double)dmin[u] + tau) continue;
-            kpp_expand<WEIGHTED>(indptr, indices, weights, dbits, dmin, mark, u, du, tau, sub, solve_base, base,
-                                 [&](int32_t v) { touched[atomicAdd(&n_touched, 1)] = v; },
-                                 [&](int32_t v) {
-                                     const int32_t p = atomicAdd(&qcnt[nxt], 1);
-                                     if (p < MICRO_QCAP) q[nxt][p] = v; else overflow = 1;
-                                 });
+        const int32_t e0 = indptr[u], e1 = indptr[u + 1];
+        for (int32_t e = e0 + sub; e < e1; e += 32) {
+            const int32_t v = indices[e];
+            const double cand = du + (WEIGHTED ? (double)weights[e] : 1.0);
+            const unsigned long long cb = (unsigned long long)__double_as_longlong(cand);
+            bool queue = false;
+            if (cb < dbits[v]) {                            // cheap pre-test (monotone: values only decrease)
+                const unsigned long long old = atomicMin(&dbits[v], cb);
+                if (cb < old && cand <= (double)dmin[v] + tau) queue = atomicMax(&mark[v], stamp) < stamp;
+            }
+            const unsigned long long m = __ballot(queue);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int32_t at = 0;
+                if (lane == leader) at = atomicAdd(&ctl->fcount[next], __popcll(m));
+                at = __shfl(at, leader, 64);
+                if (queue) fout[at + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) qcnt[cur] = 0;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        ctl->n_touched = n_touched;
-        ctl->fcount[0] = 0; ctl->fcount[1] = 0; ctl->fcount[2] = 0;
-        if (overflow) { ctl->abort_iter = pos; ctl->abort_reason = 4; }
-        else if (qcnt[sw & 1] != 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
     }
 }
 
-// d_min / argmin update over the touched nodes (kmeans_optimized.py:44 + the single-pass assignment);
-// resets their distances for the next solve.  Aborts (nothing applied) when the frontier is not empty.
+// d_min / argmin update (kmeans_optimized.py:44 + the single-pass assignment) outside the fused path below;
+// resets the solve's distances.  Aborts (nothing applied) when the frontier is not empty.
 __global__ __launch_bounds__(256) void kpp_finish_kernel(KppCtl *ctl, double *d, float *__restrict__ dmin,
-                                                        int32_t *__restrict__ argmin, const int32_t *__restrict__ touched,
-                                                        int last_next, int32_t pos) {
+                                                        int32_t *__restrict__ argmin, int32_t n, int last_next,
+                                                        int32_t pos) {
     if (ctl->abort_iter >= 0) return;
     if (ctl->fcount[last_next] != 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
         return;                                             // every block sees the same final count
     }
-    const int32_t nt = ctl->n_touched;
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += gridDim.x * blockDim.x) {
-        const int32_t v = touched[i];
-        const float x = (float)d[v];
-        if (x < dmin[v]) {
-            dmin[v] = x;
-            argmin[v] = pos;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double dd = d[i];
+        if (dd < inf64()) {
+            const float x = (float)dd;
+            if (x < dmin[i]) { dmin[i] = x; argmin[i] = pos; }
+            d[i] = inf64();
         }
-        d[v] = inf64();
     }
 }
 
@@ -252,28 +179,56 @@ __global__ __launch_bounds__(256) void kpp_fill_inf_kernel(double *__restrict__ 
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = inf64();
 }
 
-// probs = d_safe**2 with probs[centres] = 0 (kmeans_optimized.py:47-57), written for the cdf pass, and stage 1 of
-// numpy's float32 add.reduce over it (see file header): leaf sums.  8 lanes own the 8 strided accumulators
-// r[0..7] of one <=128-element leaf; they are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).
+// "Last block finishes the job": values other blocks must see inside the same launch are written and read with
+// agent-scope accesses (st_dev / ld_dev: they go to the device-coherent level, no L2 write-back or invalidate is
+// needed), every block waits for its own stores and takes a ticket, the block drawing the last ticket continues.
+template <typename T>
+__device__ __forceinline__ void st_dev(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T ld_dev(const T *p) {
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool last_block_done(int32_t *ticket) {
+    __shared__ int32_t s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    return s_last != 0;
+}
+
+// probs = d_safe**2 with probs[centres] = 0 (kmeans_optimized.py:47-57), written for the cdf pass, and numpy's
+// float32 add.reduce over it (see file header).
+//   phase 1: each block owns SUM_LEAVES consecutive leaves (<= 4096 elements); all threads compute their
+//            probabilities (coalesced) into LDS and global memory.  `fuse_finish`: the d_min / argmin update of
+//            the solve just finished (and the reset of its distances) happens here, element by element;
+//   phase 2: leaf sums -- 8 lanes own the 8 strided accumulators r[0..7] of one <=128-element leaf, combined as
+//            ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7));
+//   phase 3 (last block only): the halving tree above the leaves, then the chunk roots accumulated in order.
 // `exact_max`: the per-block maxima of kpp_max_kernel are reduced here (needed when d_min still holds inf
 // entries, which are replaced by 2*max_finite); otherwise every entry is finite and no maximum is needed.
-// `fuse_finish`: the d_min / argmin update of the solve just finished (and the reset of its distances) is done
-// here, element by element, instead of by kpp_finish_kernel -- every node is visited exactly once by the leaves.
-__global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, float *__restrict__ dmin,
-                                                      int32_t *__restrict__ argmin, double *__restrict__ d,
-                                                      int fuse_finish, int last_next, int32_t pos,
-                                                      const uint8_t *__restrict__ is_center,
-                                                      const float *__restrict__ part_max,
-                                                      const int32_t *__restrict__ part_inf, int n_part, int exact_max,
-                                                      float *__restrict__ probs,
-                                                      const int32_t *__restrict__ leaf_start,
-                                                      const int32_t *__restrict__ leaf_len, int n_leaves,
-                                                      float *__restrict__ val) {
+constexpr int SUM_LEAVES = 32, TREE_LDS_NODES = 1024;
+__global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__restrict__ dmin,
+                                                     int32_t *__restrict__ argmin, double *__restrict__ d,
+                                                     int fuse_finish, int last_next, int32_t pos,
+                                                     const uint8_t *__restrict__ is_center,
+                                                     const float *__restrict__ part_max,
+                                                     const int32_t *__restrict__ part_inf, int n_part, int exact_max,
+                                                     float *__restrict__ probs,
+                                                     const int32_t *__restrict__ leaf_start,
+                                                     const int32_t *__restrict__ leaf_len, int n_leaves,
+                                                     const int32_t *__restrict__ node_l,
+                                                     const int32_t *__restrict__ node_r,
+                                                     const int32_t *__restrict__ level_off, int n_levels,
+                                                     const int32_t *__restrict__ chunk_root, int n_chunks,
+                                                     float *val) {
     if (ctl->abort_iter >= 0) return;
     if (fuse_finish && ctl->fcount[last_next] != 0) {          // the solve did not converge: apply nothing
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
         return;
     }
+    __shared__ float sp[SUM_LEAVES * PW_BLOCK];
     __shared__ float smax;
     __shared__ int32_t sinf;
     float maxf = 0.0f;
@@ -296,17 +251,14 @@ __global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, float *__res
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->maxf = maxf; ctl->n_inf = sinf; }   // margin of the next solve
     }
     const float sub = maxf * 2.0f;
-    const int j = threadIdx.x & 7;
-    const int leaf = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const bool live = leaf < n_leaves;
-    const int32_t i0 = live ? leaf_start[leaf] : 0;
-    const int len = live ? leaf_len[leaf] : 0;
-    const int m8 = len - (len % 8);
-    auto prob_at = [&](int32_t i) {
+    const int l0 = blockIdx.x * SUM_LEAVES;
+    const int l1 = l0 + SUM_LEAVES < n_leaves ? l0 + SUM_LEAVES : n_leaves;
+    const int32_t b0 = leaf_start[l0], b1 = leaf_start[l1 - 1] + leaf_len[l1 - 1];
+    for (int32_t i = b0 + threadIdx.x; i < b1; i += 256) {
         float x = dmin[i];
         if (fuse_finish) {
             const double dd = d[i];
-            if (dd < inf64()) {                            // touched by the solve of centre `pos`
+            if (dd < inf64()) {                            // reached by the solve of centre `pos`
                 const float xd = (float)dd;
                 if (xd < x) { x = xd; dmin[i] = xd; argmin[i] = pos; }
                 d[i] = inf64();
@@ -315,130 +267,165 @@ __global__ __launch_bounds__(256) void kpp_leaf_kernel(KppCtl *ctl, float *__res
         const float safe = any_finite ? (x < inf32() ? x : sub) : 1.0f;
         const float p = is_center[i] ? 0.0f : safe * safe;
         probs[i] = p;
-        return p;
-    };
-    float r = 0.0f;
-    if (len >= 8) {
-        r = prob_at(i0 + j);
-        for (int i = 8; i < m8; i += 8) r += prob_at(i0 + i + j);
+        sp[i - b0] = p;
     }
-    // lanes (0,1) (2,3) (4,5) (6,7) -> lanes 0,2,4,6 ; then (0,2) (4,6) -> 0,4 ; then (0,4) -> 0
-    float o = __shfl_down(r, 1, 8);
-    if ((j & 1) == 0) r += o;
-    o = __shfl_down(r, 2, 8);
-    if ((j & 3) == 0) r += o;
-    o = __shfl_down(r, 4, 8);
-    if (j == 0) {
-        r += o;
-        if (len < 8) {
-            r = 0.0f;
-            for (int i = 0; i < len; ++i) r += prob_at(i0 + i);
-        } else {
-            for (int i = m8; i < len; ++i) r += prob_at(i0 + i);
+    __syncthreads();
+    {
+        const int j = threadIdx.x & 7;
+        const int leaf = l0 + (threadIdx.x >> 3);
+        const bool live = leaf < l1;
+        const float *a = sp + (live ? leaf_start[leaf] - b0 : 0);
+        const int len = live ? leaf_len[leaf] : 0;
+        const int m8 = len - (len % 8);
+        float r = 0.0f;
+        if (len >= 8) {
+            r = a[j];
+            for (int i = 8; i < m8; i += 8) r += a[i + j];
         }
-        if (live) val[leaf] = r;
+        // lanes (0,1) (2,3) (4,5) (6,7) -> lanes 0,2,4,6 ; then (0,2) (4,6) -> 0,4 ; then (0,4) -> 0
+        float o = __shfl_down(r, 1, 8);
+        if ((j & 1) == 0) r += o;
+        o = __shfl_down(r, 2, 8);
+        if ((j & 3) == 0) r += o;
+        o = __shfl_down(r, 4, 8);
+        if (j == 0) {
+            r += o;
+            if (len < 8) {
+                r = 0.0f;
+                for (int i = 0; i < len; ++i) r += a[i];
+            } else {
+                for (int i = m8; i < len; ++i) r += a[i];
+            }
+            if (live) st_dev(&val[leaf], r);
+        }
     }
-}
-
-// stage 2 (one block): the halving tree above the leaves, then the chunk roots accumulated in order.
-__global__ __launch_bounds__(1024) void kpp_tree_kernel(KppCtl *ctl, int n_leaves, const int32_t *__restrict__ node_l,
-                                                       const int32_t *__restrict__ node_r,
-                                                       const int32_t *__restrict__ level_off, int n_levels,
-                                                       const int32_t *__restrict__ chunk_root, int n_chunks,
-                                                       float *__restrict__ val, int32_t iter) {
-    if (ctl->abort_iter >= 0) return;
-    for (int lv = 0; lv < n_levels; ++lv) {
-        for (int j = level_off[lv] + threadIdx.x; j < level_off[lv + 1]; j += blockDim.x)
-            val[n_leaves + j] = val[node_l[j]] + val[node_r[j]];
+    if (!last_block_done(&ctl->ticket[0])) return;
+    __shared__ int32_t s_nl[TREE_LDS_NODES], s_nr[TREE_LDS_NODES], s_lo[32], s_cr[64];
+    const int n_nodes = level_off[n_levels];
+    float total = 0.0f;
+    if (n_nodes <= TREE_LDS_NODES && n_leaves + n_nodes <= SUM_LEAVES * PW_BLOCK && n_levels < 32 && n_chunks <= 64) {
+        // small tree: one round trip brings leaves and plan into LDS, the levels then cost LDS latency only
+        for (int j = threadIdx.x; j < n_leaves; j += 256) sp[j] = ld_dev(&val[j]);
+        for (int j = threadIdx.x; j < n_nodes; j += 256) { s_nl[j] = node_l[j]; s_nr[j] = node_r[j]; }
+        if (threadIdx.x <= n_levels) s_lo[threadIdx.x] = level_off[threadIdx.x];
+        if (threadIdx.x < n_chunks) s_cr[threadIdx.x] = chunk_root[threadIdx.x];
         __syncthreads();
+        for (int lv = 0; lv < n_levels; ++lv) {
+            for (int j = s_lo[lv] + threadIdx.x; j < s_lo[lv + 1]; j += 256) sp[n_leaves + j] = sp[s_nl[j]] + sp[s_nr[j]];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            for (int c = 0; c < n_chunks; ++c) total += sp[s_cr[c]];
+    } else {
+        for (int lv = 0; lv < n_levels; ++lv) {
+            for (int j = level_off[lv] + threadIdx.x; j < level_off[lv + 1]; j += blockDim.x)
+                st_dev(&val[n_leaves + j], ld_dev(&val[node_l[j]]) + ld_dev(&val[node_r[j]]));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            for (int c = 0; c < n_chunks; ++c) total += ld_dev(&val[chunk_root[c]]);
     }
     if (threadIdx.x == 0) {
-        float total = 0.0f;
-        for (int c = 0; c < n_chunks; ++c) total += val[chunk_root[c]];
         ctl->total = total;
-        ctl->found = 0;
-        if (!(total > 0.0f)) { ctl->abort_iter = iter; ctl->abort_reason = 3; }
+        ctl->ticket[0] = 0;
+        if (!(total > 0.0f)) { ctl->abort_iter = pos; ctl->abort_reason = 3; }
     }
 }
 
-// tile-local inclusive fp64 scan of p = float64(probs / total); tile totals
-__global__ __launch_bounds__(SCAN_T) void kpp_scan_tiles_kernel(const KppCtl *ctl, const float *__restrict__ probs,
-                                                               int32_t n, double *__restrict__ cdf,
-                                                               double *__restrict__ tile_sum) {
-    if (ctl->abort_iter >= 0) return;
-    __shared__ double wtot[SCAN_T / 64];
-    const float total = ctl->total;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
-    double v[SCAN_I];
-    double run = 0.0;
-#pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) {
-        const double p = (base + i < n) ? (double)(probs[base + i] / total) : 0.0;
-        run += p;
-        v[i] = run;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double inc = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    double wbase = 0.0, tot = 0.0;
-#pragma unroll
-    for (int w = 0; w < SCAN_T / 64; ++w) {
-        if (w < wave) wbase += wtot[w];
-        tot += wtot[w];
-    }
-    const double excl = wbase + inc - run;
-#pragma unroll
-    for (int i = 0; i < SCAN_I; ++i)
-        if (base + i < n) cdf[base + i] = excl + v[i];
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
-}
-
-// idx = searchsorted(cdf / cdf[-1], u, side='right') with a safety margin around u.  Every block first
-// rebuilds the exclusive tile offsets (sequential order, so all blocks agree bit for bit) in LDS.
-__global__ __launch_bounds__(256) void kpp_pick_kernel(KppCtl *ctl, const double *__restrict__ cdf,
-                                                      const double *__restrict__ tile_sum, int n_tiles, int32_t n,
-                                                      double u, double tol) {
+// The draw.  Every block: tile-local inclusive fp64 scan of p = float64(probs / total) and the tile total.
+// Last block: exclusive tile offsets (sequential order), idx = searchsorted(cdf / cdf[-1], u, side='right') with
+// a safety margin around u -- first the tile whose first value is the last one <= u, then the position inside
+// it -- and the commit: accept or decline the pick; on success also open the next solve.
+__global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const float *__restrict__ probs, int32_t n,
+                                                         double *cdf, double *tile_sum, int n_tiles, double u,
+                                                         double tol, int32_t *centers, uint8_t *is_center,
+                                                         int32_t next_pos, int32_t iter, int begin_next, double *d,
+                                                         int32_t *front0) {
     if (ctl->abort_iter >= 0) return;
     extern __shared__ __attribute__((aligned(16))) double toff[];          // [n_tiles + 1]
-    if (threadIdx.x == 0) {
+    __shared__ double wtot[SCAN_T / 64];
+    __shared__ int32_t s_tile, s_found, s_idx, s_ok;
+    {
+        const float total = ctl->total;
+        const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+        double v[SCAN_I];
         double run = 0.0;
-        for (int t = 0; t < n_tiles; ++t) { toff[t] = run; run += tile_sum[t]; }
-        toff[n_tiles] = run;
+#pragma unroll
+        for (int i = 0; i < SCAN_I; ++i) {
+            const double p = (base + i < n) ? (double)(probs[base + i] / total) : 0.0;
+            run += p;
+            v[i] = run;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double inc = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        double wbase = 0.0, tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < SCAN_T / 64; ++w) {
+            if (w < wave) wbase += wtot[w];
+            tot += wtot[w];
+        }
+        const double excl = wbase + inc - run;
+#pragma unroll
+        for (int i = 0; i < SCAN_I; ++i)
+            if (base + i < n) st_dev(&cdf[base + i], excl + v[i]);
+        if (threadIdx.x == 0) st_dev(&tile_sum[blockIdx.x], tot);
+    }
+    if (!last_block_done(&ctl->ticket[1])) return;
+    if (threadIdx.x < 64) {                               // exclusive tile offsets: wave scan, 64 tiles a pass
+        const int lane = threadIdx.x;
+        double carry = 0.0;
+        for (int t0 = 0; t0 < n_tiles; t0 += 64) {
+            const int t = t0 + lane;
+            const double x = t < n_tiles ? ld_dev(&tile_sum[t]) : 0.0;
+            double inc = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (t < n_tiles) toff[t] = carry + (inc - x);
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) { toff[n_tiles] = carry; s_tile = -1; s_found = 0; s_idx = -1; s_ok = 0; }
     }
     __syncthreads();
     const double s_last = toff[n_tiles];
-    for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const double cj = (cdf[j] + toff[j / SCAN_TILE]) / s_last;
-        if (j == 0 && cj > u) {                       // nothing <= u: index 0
-            ctl->found = 1; ctl->pick_idx = 0; ctl->pick_ok = (cj - u > tol) ? 1 : 0;
-        }
-        if (cj <= u) {
-            const bool last = j == n - 1;
-            const double cn = last ? inf64() : (cdf[j + 1] + toff[(j + 1) / SCAN_TILE]) / s_last;
-            if (cn > u) {
-                ctl->found = 1; ctl->pick_idx = j + 1;
-                ctl->pick_ok = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
+    auto c_at = [&](int32_t j) { return (ld_dev(&cdf[j]) + toff[j / SCAN_TILE]) / s_last; };
+    for (int t = threadIdx.x; t < n_tiles; t += SCAN_T)
+        if (c_at(t * SCAN_TILE) <= u) atomicMax(&s_tile, t);
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile < 0) {                                       // nothing <= u: index 0
+        if (threadIdx.x == 0) { s_found = 1; s_idx = 0; s_ok = (c_at(0) - u > tol) ? 1 : 0; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_I; ++k) {
+            const int32_t j = tile * SCAN_TILE + k * SCAN_T + threadIdx.x;
+            const bool in = j < n, last = j >= n - 1;
+            const double cj = in ? c_at(j) : inf64();
+            const double cn = last ? inf64() : c_at(j + 1);
+            if (in && cj <= u && cn > u) {
+                s_found = 1; s_idx = j + 1;
+                s_ok = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
             }
         }
     }
-}
-
-// accept or decline the pick; on success also open the next solve (when it runs with the multi-launch sweeps)
-__global__ void kpp_commit_kernel(KppCtl *ctl, int32_t *centers, uint8_t *is_center, int32_t next_pos, int32_t iter,
-                                  int begin_next, double *d, int32_t *mark, int32_t *touched, int32_t *front0,
-                                  int32_t next_stamp) {
-    if (ctl->abort_iter >= 0) return;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!ctl->found || !ctl->pick_ok) { ctl->abort_iter = iter; ctl->abort_reason = 2; return; }
-    centers[next_pos] = ctl->pick_idx;
-    is_center[ctl->pick_idx] = 1;
-    if (begin_next) kpp_begin(ctl, centers, next_pos, d, mark, touched, front0, next_stamp);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl->ticket[1] = 0;
+        if (!s_found || !s_ok) { ctl->abort_iter = iter; ctl->abort_reason = 2; return; }
+        centers[next_pos] = s_idx;
+        is_center[s_idx] = 1;
+        if (begin_next) kpp_begin(ctl, centers, next_pos, d, front0);
+    }
 }
 
 // ------------------------------------------------------------------ host: numpy's reduction tree
@@ -474,7 +461,7 @@ struct DevPlan {
 struct KppWs {
     KppCtl *ctl;
     double *d, *cdf, *tile_sum, *tile_off;
-    int32_t *mark, *touched, *front[2], *part_inf;
+    int32_t *mark, *front[2], *part_inf;
     float *probs, *part_max;
     DevPlan plan;
     int32_t *plan_blob;
@@ -495,7 +482,6 @@ bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
     o->tile_sum = ar.take<double>(tiles + 1);
     o->tile_off = ar.take<double>(tiles + 1);
     o->mark = ar.take<int32_t>((size_t)n);
-    o->touched = ar.take<int32_t>((size_t)n);
     o->front[0] = ar.take<int32_t>((size_t)n);
     o->front[1] = ar.take<int32_t>((size_t)n);
     o->probs = ar.take<float>((size_t)n);
@@ -513,14 +499,14 @@ extern "C" size_t geo_kpp_workspace_bytes(int32_t n) {
     if (n <= 0) return 4096;
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
     return geo::align_up(4 * sizeof(KppCtl)) + 2 * geo::align_up((size_t)n * 8) + 2 * geo::align_up((tiles + 1) * 8) +
-           6 * geo::align_up((size_t)n * 4) + 2 * geo::align_up(FINISH_GRID * 4) +
+           5 * geo::align_up((size_t)n * 4) + 2 * geo::align_up(FINISH_GRID * 4) +
            2 * geo::align_up(plan_ints_bound(n) * 4) + 4096;
 }
 
 extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
                              int32_t *centers, uint8_t *is_center, float *dmin, int32_t *argmin, const double *u_host,
                              int32_t it0, int32_t it1, int32_t n_centers_total, int32_t sweeps_per_solve,
-                             int32_t micro, int32_t assume_finite, void *ws, size_t ws_bytes, int32_t *status_out,
+                             int32_t assume_finite, void *ws, size_t ws_bytes, int32_t *status_out,
                              void *stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GEO_REQUIRE(indptr && indices && centers && is_center && dmin && argmin && ws && status_out,
@@ -573,66 +559,55 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     dp.node_r = dp.node_l + M; dp.level_off = dp.node_r + M; dp.chunk_root = dp.level_off + max_level + 1;
 
     KppCtl h0;
-    h0.abort_iter = -1; h0.abort_reason = 0; h0.n_touched = 0; h0.found = 0; h0.pick_idx = -1; h0.pick_ok = 0;
+    h0.abort_iter = -1; h0.abort_reason = 0;
     h0.fcount[0] = h0.fcount[1] = h0.fcount[2] = 0;
-    h0.total = 0.f; h0.maxf = -1.f; h0.n_inf = 0; h0.s_last = 0.0;
+    h0.ticket[0] = h0.ticket[1] = 0;
+    h0.total = 0.f; h0.maxf = -1.f; h0.n_inf = 0;
     GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, sizeof(KppCtl), hipMemcpyHostToDevice, s));
     GEO_HIP_CHECK(hipMemsetAsync(w.mark, 0, (size_t)n * 4, s));
 
     const int g_lin = geo::grid_for(n, 256, 2048);
     // frontier sweeps: the first solves cross the whole graph, later ones only the new centre's (pruned)
     // cell, where a small grid keeps the launch itself cheap
-    const int g_push_big = geo::grid_for(n, 32, 2048), g_push_small = geo::grid_for(n, 32, 256);
+    const char *gcap = getenv("GEO_KPP_GRID");
+    const int g_push_big = geo::grid_for(n, 32, 2048), g_push_small = geo::grid_for(n, 32, gcap ? atoi(gcap) : 256);
     const int n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     const double tol = ((double)n + 16.0) * 4.440892098500626e-16;            // (n+16) * 2^-51
     const int exact_max = assume_finite ? 0 : 1;     // with every d_min finite no maximum is needed for the draw
     kpp_fill_inf_kernel<<<g_lin, 256, 0, s>>>(w.d, n);
     kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max, w.part_inf);
     kpp_maxfin_kernel<<<1, 64, 0, s>>>(w.ctl, w.part_max, w.part_inf, FINISH_GRID);
-    if (!micro && it0 < it1)
-        kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, it0, w.d, w.mark, w.touched, w.front[0], 1);
+    if (it0 < it1) kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, it0, w.d, w.front[0]);
     GEO_LAUNCH_CHECK();
     for (int32_t t = it0; t < it1; ++t) {
         const int32_t stamp_solve = (t - it0) + 1;
         int last_next = 0;
-        if (micro) {
+        const int g_push = t < 16 ? g_push_big : g_push_small;
+        for (int sw = 0; sw < sweeps_per_solve; ++sw) {
+            const int cur = sw % 3, next = (sw + 1) % 3, clear = (sw + 2) % 3;
             if (weights)
-                kpp_micro_kernel<true><<<1, 1024, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark, w.touched,
-                                                          centers, t, stamp_solve, 4000);
+                kpp_push_kernel<true><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark,
+                                                             w.front[sw & 1], w.front[(sw + 1) & 1], cur, next, clear,
+                                                             stamp_solve, sw);
             else
-                kpp_micro_kernel<false><<<1, 1024, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark, w.touched,
-                                                           centers, t, stamp_solve, 4000);
-        } else {
-            const int g_push = t < 16 ? g_push_big : g_push_small;
-            for (int sw = 0; sw < sweeps_per_solve; ++sw) {
-                const int cur = sw % 3, next = (sw + 1) % 3, clear = (sw + 2) % 3;
-                if (weights)
-                    kpp_push_kernel<true><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark, w.touched,
-                                                                 w.front[sw & 1], w.front[(sw + 1) & 1], cur, next, clear,
-                                                                 stamp_solve, sw);
-                else
-                    kpp_push_kernel<false><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark, w.touched,
-                                                                  w.front[sw & 1], w.front[(sw + 1) & 1], cur, next, clear,
-                                                                  stamp_solve, sw);
-                last_next = next;
-            }
+                kpp_push_kernel<false><<<g_push, 256, 0, s>>>(w.ctl, indptr, indices, weights, w.d, dmin, w.mark,
+                                                              w.front[sw & 1], w.front[(sw + 1) & 1], cur, next, clear,
+                                                              stamp_solve, sw);
+            last_next = next;
         }
-        const int fuse = (!exact_max && t + 1 < n_centers_total) ? 1 : 0;
+        const bool draw = t + 1 < n_centers_total;
+        const int fuse = (!exact_max && draw) ? 1 : 0;
         if (!fuse)
-            kpp_finish_kernel<<<geo::grid_for(n, 256, 256), 256, 0, s>>>(w.ctl, w.d, dmin, argmin, w.touched, last_next, t);
-        if (t + 1 < n_centers_total) {
+            kpp_finish_kernel<<<geo::grid_for(n, 256, 256), 256, 0, s>>>(w.ctl, w.d, dmin, argmin, n, last_next, t);
+        if (draw) {
             if (exact_max) kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max, w.part_inf);
-            kpp_leaf_kernel<<<(dp.n_leaves * 8 + 255) / 256, 256, 0, s>>>(w.ctl, dmin, argmin, w.d, fuse, last_next, t,
-                                                                          is_center, w.part_max, w.part_inf,
-                                                                          FINISH_GRID, exact_max, w.probs, dp.leaf_start,
-                                                                          dp.leaf_len, dp.n_leaves, dp.val);
-            kpp_tree_kernel<<<1, 1024, 0, s>>>(w.ctl, dp.n_leaves, dp.node_l, dp.node_r, dp.level_off, dp.n_levels,
-                                               dp.chunk_root, dp.n_chunks, dp.val, t);
-            kpp_scan_tiles_kernel<<<n_tiles, SCAN_T, 0, s>>>(w.ctl, w.probs, n, w.cdf, w.tile_sum);
-            kpp_pick_kernel<<<g_lin, 256, (size_t)(n_tiles + 1) * sizeof(double), s>>>(w.ctl, w.cdf, w.tile_sum, n_tiles,
-                                                                                       n, u_host[t], tol);
-            kpp_commit_kernel<<<1, 64, 0, s>>>(w.ctl, centers, is_center, t + 1, t, (!micro && t + 1 < it1) ? 1 : 0, w.d,
-                                               w.mark, w.touched, w.front[0], stamp_solve + 1);
+            kpp_sum_kernel<<<(dp.n_leaves + SUM_LEAVES - 1) / SUM_LEAVES, 256, 0, s>>>(
+                w.ctl, dmin, argmin, w.d, fuse, last_next, t, is_center, w.part_max, w.part_inf, FINISH_GRID, exact_max,
+                w.probs, dp.leaf_start, dp.leaf_len, dp.n_leaves, dp.node_l, dp.node_r, dp.level_off, dp.n_levels,
+                dp.chunk_root, dp.n_chunks, dp.val);
+            kpp_draw_kernel<<<n_tiles, SCAN_T, (size_t)(n_tiles + 1) * sizeof(double), s>>>(
+                w.ctl, w.probs, n, w.cdf, w.tile_sum, n_tiles, u_host[t], tol, centers, is_center, t + 1, t,
+                t + 1 < it1 ? 1 : 0, w.d, w.front[0]);
         }
         GEO_LAUNCH_CHECK();
     }

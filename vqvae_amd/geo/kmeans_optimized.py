@@ -133,27 +133,18 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
     it, it1 = 0, (K if absorb_last else K - 1)
     n_valid = K
-    # Solves: the first `warm` centres cross most of the graph -> multi-launch frontier sweeps; afterwards the
-    # pruned cells are small -> one-workgroup solves (LDS queues).  A solve that outgrows the queue, or needs
-    # more sweeps than were enqueued, aborts harmlessly and is redone another way.
+    # Solves: the first `warm` centres cross most of the graph and get twice the sweeps; afterwards the pruned
+    # cells are small.  A solve that needs more sweeps than were enqueued aborts harmlessly and is redone by
+    # the host-driven single-source solve.
     sweeps, warm = int(os.environ.get("GEO_KPP_SWEEPS", "7")), 16
-    # one-workgroup solves only win for frontiers of a few dozen nodes (32 lane groups per workgroup); at the
-    # shipped sizes the cells hold hundreds to thousands of nodes, so this stays opt-in
-    use_micro = os.environ.get("GEO_KPP_MICRO", "0") == "1"
-    finite, redo_multi = False, False
+    finite = False
     status = np.zeros(4, dtype=np.int32)
     while it < it1:
-        if it < warm:
-            seg_end, micro, sw = min(it1, warm), 0, 2 * sweeps
-        elif redo_multi or not use_micro:
-            seg_end, micro, sw = (it + 1 if redo_multi else it1), 0, (2 * sweeps if redo_multi else sweeps)
-        else:
-            seg_end, micro, sw = it1, 1, sweeps
-        redo_multi = False
+        seg_end, sw = (min(it1, warm), 2 * sweeps) if it < warm else (it1, sweeps)
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
                                          ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
-                                         K, sw, micro, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
+                                         K, sw, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
                                          stream_ptr()),
                        "geo_kpp_chain")
         t, reason = int(status[0]), int(status[1])
@@ -163,9 +154,6 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
             it = seg_end
             continue
         chain.solves += t - it + 1
-        if reason == 4:                                  # cell too large for the one-workgroup queue: nothing applied
-            redo_multi, it = True, t
-            continue
         centers_h = centers_d[: t + 1].cpu().numpy().astype(int).tolist()
         if reason == 1:                                  # this solve needs more sweeps: host-driven solve
             sweeps = min(2 * sweeps, 2048)
