@@ -43,6 +43,9 @@ WORKLOADS = {
     "c1": (2048, 16, 1, 28, 20, 64),
     "c2": (60000, 16, 1, 28, 20, 512),
     "c3": (50000, 32, 3, 32, 20, 512),
+    # second latent distribution -- noisy 2-D swiss roll embedded in d dims (long geodesics,
+    # many relaxation sweeps); same decoder / k / K as c2
+    "swiss": (60000, 16, 1, 28, 20, 512),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -51,10 +54,22 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def swiss_roll(n, d, seed):
+    """Noisy 2-D swiss roll in the first three coordinates, small isotropic noise in all d (unit-ish scale)."""
+    r = np.random.RandomState(seed)
+    t = 1.5 * np.pi * (1.0 + 2.0 * r.rand(n))
+    h = 21.0 * r.rand(n)
+    x = np.zeros((n, d), dtype=np.float64)
+    x[:, 0], x[:, 1], x[:, 2] = t * np.cos(t), h, t * np.sin(t)
+    x = x / 7.0 + 0.02 * r.randn(n, d)
+    return x.astype(np.float32)
+
+
 def make_inputs(name, dev):
     from vqvae_amd.spatial_decoder import SpatialDecoder
     n, d, cout, size, k, K = WORKLOADS[name]
-    z = torch.from_numpy(np.random.RandomState(0).randn(n, d).astype(np.float32)).to(dev)
+    z = torch.from_numpy(swiss_roll(n, d, 0) if name == "swiss"
+                         else np.random.RandomState(0).randn(n, d).astype(np.float32)).to(dev)
     torch.manual_seed(0)
     dec = SpatialDecoder(cout, (256, 128, 64), d, size, "batch").to(dev).train()    # random init, BN in train mode
     return z, dec, dict(n=n, d=d, k=k, K=K, size=size, cout=cout)

@@ -82,7 +82,8 @@ int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const 
  * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged).
  * assume_finite != 0 promises that d_min has no inf entry left (status_out[2] of an earlier call): the
  * per-iteration maximum pass is skipped.
- * status_out [host, 3 ints]: {abort_iter or -1, reason, inf entries of d_min at the last maximum pass}:
+ * status_out [host, 4 ints]: {abort_iter or -1, reason, inf entries of d_min at the last maximum pass,
+ * most sweeps any solve of this call needed}:
  * reason 1 = solve not converged (nothing of that iteration is applied), 2 = u too close to a cdf boundary,
  * 3 = degenerate weights (for 2 and 3 the solve of that iteration IS applied, the draw is not).  The caller
  * repeats that step another way and resumes.

@@ -40,6 +40,7 @@ struct KppCtl {
     float total;
     float maxf;                            // max finite d_min (-1: none), basis of the pruning margin
     int32_t n_inf;                         // unreachable (inf) entries of d_min at the last max pass
+    int32_t max_sw;                        // most sweeps any solve of this call needed (non-empty frontiers)
 };
 
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
     const int32_t cnt = ctl->fcount[cur];
     if (cnt == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sw + 1 > ctl->max_sw) ctl->max_sw = sw + 1;   // launches are serial
     const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
     const int sub = threadIdx.x & 31, lane = threadIdx.x & 63;       // 32 lanes per frontier node (mean degree ~31)
     const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -562,7 +564,7 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     h0.abort_iter = -1; h0.abort_reason = 0;
     h0.fcount[0] = h0.fcount[1] = h0.fcount[2] = 0;
     h0.ticket[0] = h0.ticket[1] = 0;
-    h0.total = 0.f; h0.maxf = -1.f; h0.n_inf = 0;
+    h0.total = 0.f; h0.maxf = -1.f; h0.n_inf = 0; h0.max_sw = 0;
     GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, sizeof(KppCtl), hipMemcpyHostToDevice, s));
     GEO_HIP_CHECK(hipMemsetAsync(w.mark, 0, (size_t)n * 4, s));
 
@@ -617,5 +619,6 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     status_out[0] = h1.abort_iter;
     status_out[1] = h1.abort_reason;
     status_out[2] = h1.n_inf;                 // unreachable entries of d_min at the last maximum pass
+    status_out[3] = h1.max_sw;                // sweeps the longest solve of this call used
     return GEO_OK;
 }

@@ -20,6 +20,7 @@
 #include "geo_common.h"
 #include "sssp_device.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -179,12 +180,17 @@ __global__ __launch_bounds__(256) void chunk_fill_kernel(const int32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void source_bits_kernel(const int32_t *__restrict__ src, int32_t n_sources, int32_t n,
-                                                         int32_t sb, int32_t words, uint32_t *__restrict__ bits) {
-    uint8_t *map = reinterpret_cast<uint8_t *>(bits);                    // one byte per (batch, node)
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sources; i += gridDim.x * blockDim.x) {
+// first sweep's need-map: the neighbours of every source (one byte per (batch, node))
+__global__ __launch_bounds__(256) void source_need_kernel(const int32_t *__restrict__ src, int32_t n_sources, int32_t n,
+                                                         int32_t sb, int32_t words, const int32_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices, uint32_t *__restrict__ bits) {
+    uint8_t *map = reinterpret_cast<uint8_t *>(bits);
+    const int sub = threadIdx.x & 15;
+    for (int32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_sources; i += (gridDim.x * blockDim.x) >> 4) {
         const int32_t v = src[i];
-        if (v >= 0 && v < n) map[(size_t)(i / sb) * words * 4 + v] = 1;
+        if (v < 0 || v >= n) continue;
+        uint8_t *m = map + (size_t)(i / sb) * words * 4;
+        for (int32_t e = indptr[v] + sub; e < indptr[v + 1]; e += 16) m[indices[e]] = 1;
     }
 }
 
@@ -198,7 +204,8 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
                                                            int32_t *flags, int32_t *counts,
                                                            const uint32_t *__restrict__ bits_prev,
                                                            uint32_t *__restrict__ bits_cur, int32_t words, int prev,
-                                                           int cur, int next, int first, int act_mode) {
+                                                           int cur, int next, int first, int act_mode,
+                                                           int sparse_div, int map_div) {
     const int bid = blockIdx.x;
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
@@ -207,14 +214,14 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     const int xb = (bid % (gs * blocks_per_batch)) / gs;
     if (b >= nb) return;
     if (!first && flags[prev * nb + b] == 0) return;                     // fixed point reached for this batch
-    // the neighbour-activity test only pays when few rows moved (first sweeps, last sweeps): `counts` holds a
-    // 1-in-16 block sample of the number of improved chunk slots of the previous sweep
+    // visiting only flagged rows pays when few rows moved (first sweeps, last sweeps): `counts` holds a
+    // 1-in-16 block sample of the number of improved (node, source) pairs of the previous sweep
     // counts[.] >= 0: sampled count, map written;  < 0: -(sampled count), map NOT written by that sweep
     const int32_t cp = first ? 0 : counts[prev * nb + b];
     const int32_t est_prev = (cp >= 0 ? cp : -cp) * 16;
-    const bool sparse_sweep = act_mode && (first || (cp >= 0 && est_prev < (n >> 3) * 16));
-    // the activity map costs a scattered byte store per improved slot: keep it only while few rows move
-    const bool write_map = act_mode && (first || est_prev < (n >> 1) * 16);
+    const bool sparse_sweep = act_mode && (first || (cp >= 0 && (int64_t)est_prev * sparse_div < (int64_t)n * 16));
+    // flagging costs a scattered byte store per edge of every improved row: keep it only while few rows move
+    const bool write_map = sparse_sweep || (act_mode && (int64_t)est_prev * map_div < (int64_t)n * 16);
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[next * nb + i] = 0;
 
@@ -223,11 +230,12 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     const unsigned s = lane & 15;
     double *D = dist + (size_t)b * n * 16;
     unsigned long long *Dbits = reinterpret_cast<unsigned long long *>(D);
-    // activity: a chunk is re-evaluated only if one of its 16 neighbours had a distance lowered (for any of
-    // this batch's 16 sources) during the previous sweep.  Every change is followed by an evaluation of its
-    // dependents in the next sweep, so the fixed point is the same; sweeps 1-2 and the last ones touch a
-    // small part of the graph.  One byte per (batch, node); `bits_prev` was filled by the previous sweep.
-    // (a byte per node, set with plain idempotent stores: no atomics on a few hot cache lines)
+    // need-map: one byte per (batch, node), "a neighbour's distance was lowered (for any of this batch's 16
+    // sources) during the previous sweep".  A row that improves sets the byte of all its neighbours with plain
+    // idempotent stores (no atomics); every change is thus followed by an evaluation of its dependents in the
+    // next sweep, so the fixed point is the same, and sweeps in which few rows move (the first ones, the last
+    // ones, and every sweep of a long-geodesic graph) only touch the flagged rows.  `bits_prev` was filled by
+    // the previous sweep (by source_need_kernel before the first).
     const uint8_t *bp = reinterpret_cast<const uint8_t *>(bits_prev) + (size_t)b * words * 4;
     uint8_t *bc = reinterpret_cast<uint8_t *>(bits_cur) + (size_t)b * words * 4;
     const int slot_in_wave = lane >> 4;
@@ -242,26 +250,25 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     relax_edge16<12>(D, s, idx, wb, best); relax_edge16<13>(D, s, idx, wb, best);                           \
     relax_edge16<14>(D, s, idx, wb, best); relax_edge16<15>(D, s, idx, wb, best)
     if (sparse_sweep) {
-        // few rows moved last sweep: test the 16 neighbours' activity bytes first, skip idle slots
-        for (int32_t c0 = xb * 16; c0 < n_chunks; c0 += blocks_per_batch * 16) {
-            const int32_t c = c0 + slot_in_block;
-            const bool live = c < n_chunks;
-            const int32_t v = live ? chunk_node[c] : 0, e = live ? chunk_start[c] : 0;
-            const int32_t cnt = live ? indptr[v + 1] - e : 0;
-            const bool has = (int)s < cnt;
-            const int idx = has ? indices[e + s] : v;
-            const bool hot = has && bp[idx] != 0;
-            const unsigned long long hot_mask = __ballot(hot);
-            if (((hot_mask >> (slot_in_wave * 16)) & 0xffffull) == 0) continue;  // whole slot idle this sweep
-            const int wb = has ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+        // few rows moved last sweep: a 16-lane slot takes a whole row, and only flagged rows are evaluated
+        for (int32_t v = xb * 16 + slot_in_block; v < n; v += blocks_per_batch * 16) {
+            if (bp[v] == 0) continue;                                            // slot-uniform
+            const int32_t e0 = indptr[v], e1 = indptr[v + 1];
             const double curv = D[(unsigned)v * 16u + s];
             double best = curv;
-            GEO_RELAX16_ALL();
-            if (best < curv) {
+            for (int32_t e = e0; e < e1; e += 16) {
+                const int32_t cnt = e1 - e;
+                const int idx = ((int)s < cnt) ? indices[e + s] : v;
+                const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+                GEO_RELAX16_ALL();
+            }
+            const bool better = best < curv;
+            if (better) {
                 atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
-                bc[v] = 1;                                   // same byte for the slot's lanes: one merged store
                 ++n_better;
             }
+            if ((__ballot(better) >> (slot_in_wave * 16)) & 0xffffull)           // the row moved: flag its neighbours
+                for (int32_t e = e0 + (int)s; e < e1; e += 16) bc[indices[e]] = 1;
         }
     } else {
         // dense sweep: straight-line body, no wave-level votes between a chunk's loads and the next chunk's
@@ -273,11 +280,13 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
             const double curv = D[(unsigned)v * 16u + s];
             double best = curv;
             GEO_RELAX16_ALL();
-            if (best < curv) {
+            const bool better = best < curv;
+            if (better) {
                 atomicMin(&Dbits[(unsigned)v * 16u + s], (unsigned long long)__double_as_longlong(best));
-                if (write_map) bc[v] = 1;
                 ++n_better;
             }
+            if (write_map && ((__ballot(better) >> (slot_in_wave * 16)) & 0xffffull))   // flag ALL neighbours of v
+                for (int32_t e2 = indptr[v] + (int)s; e2 < indptr[v + 1]; e2 += 16) bc[indices[e2]] = 1;
         }
     }
 #undef GEO_RELAX16_ALL
@@ -290,10 +299,11 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     }
 }
 
-// dist[b][v][s] -> out[(b*sb+s)][v], 64-node x sb-source tiles through LDS.
+// dist[b][v][s] -> out[row_of[b*sb+s]][v], 64-node x sb-source tiles through LDS.
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void transpose_out_kernel(const TIn *__restrict__ in, TOut *__restrict__ out,
-                                                           int32_t n, int32_t n_sources, int32_t sb) {
+                                                           int32_t n, int32_t n_sources, int32_t sb,
+                                                           const int32_t *__restrict__ row_of) {
     __shared__ TOut tile[64][65];
     const int b = blockIdx.y;
     const int32_t v0 = blockIdx.x * 64;
@@ -304,32 +314,32 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const TIn *__restric
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * sb; i += 256) {
         const int si = i / 64, vi = i % 64;
-        const int32_t row = b * sb + si;
-        if (row < n_sources && v0 + vi < n) out[(size_t)row * n + v0 + vi] = tile[vi][si];
+        const int32_t slot = b * sb + si;                   // row_of: the caller's row of this (batch, slot)
+        if (slot < n_sources && v0 + vi < n) out[(size_t)row_of[slot] * n + v0 + vi] = tile[vi][si];
     }
 }
 
 // Column minimum of the f32 matrix and the first row attaining it (D.argmin(axis=0)).
 __global__ __launch_bounds__(256) void colmin_kernel(const double *__restrict__ dist, int32_t n, int32_t n_sources,
-                                                    int32_t sb, float *__restrict__ dmin,
-                                                    int32_t *__restrict__ argmin) {
+                                                    int32_t sb, const int32_t *__restrict__ row_of,
+                                                    float *__restrict__ dmin, int32_t *__restrict__ argmin) {
     const int lane = threadIdx.x & 63;
     const int32_t v = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (v >= n) return;
     float best = __int_as_float(0x7f800000);
-    int32_t barg = 0;
-    for (int32_t r0 = 0; r0 < n_sources; r0 += 64) {           // 64 consecutive source rows per step
+    int32_t barg = 0x7fffffff;
+    for (int32_t r0 = 0; r0 < n_sources; r0 += 64) {           // 64 consecutive source slots per step
         const int32_t row = r0 + lane;
         float val = __int_as_float(0x7f800000);
         if (row < n_sources) val = (float)dist[((size_t)(row / sb) * n + v) * sb + (row % sb)];
-        int32_t idx = row;
+        int32_t idx = row < n_sources ? row_of[row] : 0x7fffffff;     // ties: lowest row of the CALLER's order
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const float ov = __shfl_xor(val, off, 64);
             const int32_t oi = __shfl_xor(idx, off, 64);
             if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
         }
-        if (val < best) { best = val; barg = idx; }
+        if (val < best || (val == best && idx < barg)) { best = val; barg = idx; }
     }
     if (lane == 0) {
         if (dmin) dmin[v] = best;
@@ -404,6 +414,43 @@ int32_t g_last_sweep_launches = 0;
 int32_t g_last_layout = 0;             // sources per batch of the last geo_sssp_multi call, +1000 when chunked
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
+// fp64 single-source solve into d[n] (flags: 4 ints); `group` sweeps between convergence checks
+int solve_single(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n, int32_t source,
+                 double *d, int32_t *flags, int group, hipStream_t stream, int32_t *sweeps_out) {
+    init_single_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(d, n, source, flags);
+    GEO_LAUNCH_CHECK();
+    const int grid = geo::grid_for(n, 16, 2048);      // 16 nodes per 256-thread block
+    int32_t sweeps = 0, hflag = 1;
+    const int64_t limit = (int64_t)n + 2;
+    while (hflag) {
+        int last_cur = 0;
+        for (int g = 0; g < group; ++g, ++sweeps) {
+            const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
+            if (weights)
+                sweep_single_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
+                                                                    next, sweeps == 0);
+            else
+                sweep_single_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
+                                                                     next, sweeps == 0);
+            GEO_LAUNCH_CHECK();
+            last_cur = cur;
+        }
+        GEO_HIP_CHECK(hipMemcpyAsync(&hflag, flags + last_cur, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (hflag && sweeps > limit) {
+            geo::set_error("single-source solve: no fixed point after %d sweeps", sweeps);
+            return GEO_E_NOCONV;
+        }
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    return GEO_OK;
+}
+
+__global__ void gather_f32_kernel(const double *__restrict__ d, const int32_t *__restrict__ at, int32_t m,
+                                  float *__restrict__ out) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = (float)d[at[i]];
+}
+
 struct MultiWs {
     double *dist;
     int32_t *pred;
@@ -432,13 +479,13 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     const size_t words = ((size_t)n + 3) / 4;
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
-           geo::align_up(3 * (size_t)nb * 4);
+           geo::align_up(3 * (size_t)nb * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) + 256;
 }
 
 size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
     size_t b = geo::align_up((size_t)nb * n * sb * sizeof(double));
     if (with_pred) b += geo::align_up((size_t)nb * n * sb * sizeof(int32_t));
-    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + geo::align_up((size_t)nb * sb * sizeof(int32_t));
+    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + 2 * geo::align_up((size_t)nb * sb * sizeof(int32_t));
     return b;
 }
 
@@ -479,35 +526,34 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     w.pred = P_out ? ar.take<int32_t>((size_t)nb * n * sb) : nullptr;
     w.flags = ar.take<int32_t>(3 * (size_t)nb);
     w.src_pad = ar.take<int32_t>((size_t)nb * sb);
-
-    GEO_HIP_CHECK(hipMemsetAsync(w.src_pad, 0xff, (size_t)nb * sb * sizeof(int32_t), stream));   // -1 = no source
-    GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, sources, (size_t)n_sources * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-    GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)nb * sizeof(int32_t), stream));
-    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
-    GEO_LAUNCH_CHECK();
+    int32_t *row_of = ar.take<int32_t>((size_t)nb * sb);          // (batch, slot) -> row of the caller's `sources`
 
     int32_t *chunk_node = nullptr, *chunk_start = nullptr;
     uint32_t *bits = nullptr;
     int32_t *counts = nullptr;
+    double *lm_d = nullptr;
+    float *lm_key = nullptr;
+    int32_t *lm_flags = nullptr;
     const int act_mode = getenv("GEO_SSSP_ACT") ? atoi(getenv("GEO_SSSP_ACT")) : 1;
-    const int32_t words = (n + 3) / 4;                       // activity map: one byte per node, in 4-byte words
+    // sparse body while fewer than n/sparse_div rows moved in the previous sweep; map kept below n/map_div
+    const int sparse_div = getenv("GEO_SSSP_SPARSE_DIV") ? atoi(getenv("GEO_SSSP_SPARSE_DIV")) : 8;
+    const int map_div = getenv("GEO_SSSP_MAP_DIV") ? atoi(getenv("GEO_SSSP_MAP_DIV")) : 2;
+    const int group_mode = getenv("GEO_SSSP_GROUP") ? atoi(getenv("GEO_SSSP_GROUP")) : 1;   // 0 never, 1 auto, 2 always
+    const int32_t words = (n + 3) / 4;                       // need-map: one byte per node, in 4-byte words
     int64_t n_chunks = 0;
     if (chunked) {
         bits = ar.take<uint32_t>(3 * (size_t)nb * words);
         counts = ar.take<int32_t>(3 * (size_t)nb);
-        GEO_REQUIRE(bits != nullptr && counts != nullptr, "geo_sssp_multi: workspace carve failed");
-        GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * (size_t)nb * 4, stream));
-        GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb * words * 4, stream));
-        source_bits_kernel<<<geo::grid_for(n_sources, 256, 64), 256, 0, stream>>>(w.src_pad, n_sources, n, sb, words,
-                                                                                   bits + 2 * (size_t)nb * words);
-        GEO_LAUNCH_CHECK();
         int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
         const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
         chunk_node = ar.take<int32_t>(max_chunks);
         chunk_start = ar.take<int32_t>(max_chunks);
         const size_t sbytes = geo::scan_tmp_bytes((int64_t)n + 1);
         void *stmp = ar.take<char>(sbytes);
-        GEO_REQUIRE(stmp != nullptr, "geo_sssp_multi: workspace carve failed");
+        lm_d = ar.take<double>((size_t)n);
+        lm_key = ar.take<float>(2 * (size_t)nb * sb);
+        lm_flags = ar.take<int32_t>(4);
+        GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags, "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
         int rc = geo::exclusive_scan_i32(ccnt, coff, n, stmp, sbytes, &n_chunks, stream);
@@ -521,64 +567,154 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     const int gs = nb < 8 ? nb : 8;
     const int groups = (nb + gs - 1) / gs;
     const int cap = 65536 / (gs * groups);
-    const int per_batch = chunked ? geo::grid_for(n_chunks, 16, cap > 0 ? cap : 1)
-                                  : geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
-    const unsigned grid = (unsigned)per_batch * (unsigned)gs * (unsigned)groups;
-    std::vector<int32_t> hflags(nb);
-    int32_t sweeps = 0;
-    bool done = false;
-    const int64_t limit = (int64_t)n + 2;
+    std::vector<int32_t> hflags(nb), hcounts(nb), order(n_sources), hsrc, host_sources(n_sources);
+    for (int32_t i = 0; i < n_sources; ++i) order[i] = i;
+    GEO_HIP_CHECK(hipMemcpyAsync(host_sources.data(), sources, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+    GEO_HIP_CHECK(hipStreamSynchronize(stream));
     if (!g_ev0) {
         GEO_HIP_CHECK(hipEventCreate(&g_ev0));
         GEO_HIP_CHECK(hipEventCreate(&g_ev1));
     }
     g_last_sweep_ms = 0.0;
-    while (!done) {
-        int last_cur = 0;
-        GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
-        for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
-            const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
+    int32_t total_sweeps = 0;
+    bool grouped = false;
+    // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
+    // sources moved a neighbour, so with 16 scattered sources every row is re-evaluated as each of 16 fronts
+    // passes (and their corrections cascade), with 16 neighbouring sources the fronts pass as one.  On graphs
+    // with short geodesics (a few sweeps) this does not matter; when the first sweeps reach only a small part
+    // of the graph the solve restarts with the sources ordered along two landmark distances (Morton order of
+    // (dist from sources[0], dist from the source farthest from it)).  Results do not depend on the grouping.
+    for (int attempt = 0;; ++attempt) {
+        hsrc.assign((size_t)nb * sb, -1);                           // -1 = no source in this slot
+        std::vector<int32_t> hrow((size_t)nb * sb, -1);
+        for (int32_t i = 0; i < n_sources; ++i) { hsrc[i] = host_sources[order[i]]; hrow[i] = order[i]; }
+        GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, hsrc.data(), hsrc.size() * 4, hipMemcpyHostToDevice, stream));
+        GEO_HIP_CHECK(hipMemcpyAsync(row_of, hrow.data(), hrow.size() * 4, hipMemcpyHostToDevice, stream));
+        GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)nb * sizeof(int32_t), stream));
+        init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
+        GEO_LAUNCH_CHECK();
+        if (chunked) {
+            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * (size_t)nb * 4, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb * words * 4, stream));
+            source_need_kernel<<<geo::grid_for((int64_t)n_sources * 16, 256, 256), 256, 0, stream>>>(
+                w.src_pad, n_sources, n, sb, words, indptr, indices, bits + 2 * (size_t)nb * words);
+            GEO_LAUNCH_CHECK();
+        }
+        // grouped solves run many sweeps that touch few rows: a smaller grid keeps the idle launches cheap
+        const char *gcap = getenv("GEO_SSSP_GROUPED_CAP");
+        const int want_cap = gcap ? atoi(gcap) : 256;
+        const int cap_now = (grouped && cap > want_cap) ? want_cap : cap;
+        // ... and stay with the flagged-row body whenever the need-map is there
+        const int sdiv = grouped && !getenv("GEO_SSSP_SPARSE_DIV") ? 1 : sparse_div;
+        const int mdiv = grouped && !getenv("GEO_SSSP_MAP_DIV") ? 1 : map_div;
+        const int per_batch = chunked ? geo::grid_for(n_chunks, 16, cap_now > 0 ? cap_now : 1)
+                                      : geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
+        const unsigned grid = (unsigned)per_batch * (unsigned)gs * (unsigned)groups;
+        int32_t sweeps = 0;
+        bool done = false, regroup = false;
+        const int64_t limit = (int64_t)n + 2;
+        int group_len = SWEEP_GROUP;
+        while (!done && !regroup) {
+            int last_cur = 0;
+            GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
+            for (int g = 0; g < group_len; ++g, ++sweeps) {
+                const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
 #define GEO_SWEEP(SBT, WT)                                                                                          \
     sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, gs, w.dist, w.flags, \
                                                           prev, cur, next, sweeps == 0)
-            if (chunked) {
-                uint32_t *bcur = bits + (size_t)cur * nb * words, *bprev = bits + (size_t)prev * nb * words;
-                if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb * words * 4, stream));
-                if (weights)
-                    sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
-                                                                         (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                         counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode);
-                else
-                    sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
-                                                                          (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                          counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode);
-            } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
-            else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
+                if (chunked) {
+                    uint32_t *bcur = bits + (size_t)cur * nb * words, *bprev = bits + (size_t)prev * nb * words;
+                    if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb * words * 4, stream));
+                    if (weights)
+                        sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
+                                                                             (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
+                                                                             counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv);
+                    else
+                        sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
+                                                                              (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
+                                                                              counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv);
+                } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
+                else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
-            GEO_LAUNCH_CHECK();
-            last_cur = cur;
+                GEO_LAUNCH_CHECK();
+                if (chunked && getenv("GEO_SSSP_TRACE")) {            // experiment: sampled improvement counts per sweep
+                    std::vector<int32_t> hc(nb);
+                    GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)cur * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));
+                    long long tot = 0, neg = 0;
+                    for (int32_t b = 0; b < nb; ++b) { tot += hc[b] < 0 ? -hc[b] : hc[b]; neg += hc[b] < 0; }
+                    fprintf(stderr, "[sssp] sweep %d: ~%lld improved pairs (%.1f%% of pairs), %lld/%d batches without map\n", sweeps,
+                            tot * 16, 100.0 * tot * 16 / ((double)nb * n * 16), neg, nb);
+                }
+                last_cur = cur;
+            }
+            GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
+            GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
+                                         hipMemcpyDeviceToHost, stream));
+            if (chunked)
+                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data(), counts + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
+                                             hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            float ms = 0.f;
+            GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+            g_last_sweep_ms += ms;
+            done = true;
+            for (int32_t b = 0; b < nb; ++b) done = done && (hflags[b] == 0);
+            if (!done && sweeps > limit) {
+                geo::set_error("geo_sssp_multi: no fixed point after %d sweeps", sweeps);
+                return GEO_E_NOCONV;
+            }
+            if (!done && chunked && !grouped && group_mode != 0 && attempt == 0 && sweeps == SWEEP_GROUP) {
+                // after the first sweeps: how much of the (node, source) matrix moved in the last one?
+                double moved = 0.0;
+                for (int32_t b = 0; b < nb; ++b) moved += 16.0 * (hcounts[b] < 0 ? -hcounts[b] : hcounts[b]);
+                regroup = group_mode == 2 || moved < 0.25 * (double)nb * n * 16;
+            }
+            if (sweeps >= 16 && group_len < 16) group_len *= 2;      // long solves: fewer host round trips
         }
-        GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
-        GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
-                                     hipMemcpyDeviceToHost, stream));
-        GEO_HIP_CHECK(hipStreamSynchronize(stream));
-        float ms = 0.f;
-        GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
-        g_last_sweep_ms += ms;
-        done = true;
-        for (int32_t b = 0; b < nb; ++b) done = done && (hflags[b] == 0);
-        if (!done && sweeps > limit) {
-            geo::set_error("geo_sssp_multi: no fixed point after %d sweeps", sweeps);
-            return GEO_E_NOCONV;
+        total_sweeps += sweeps;
+        if (done) break;
+        // ---- order the sources along two landmark distances, then start over ----
+        {
+            int32_t lm_sweeps = 0;
+            std::vector<float> ka(n_sources), kb(n_sources);
+            const int gk = geo::grid_for(n_sources, 256, 64);
+            if (int rc = solve_single(indptr, indices, weights, n, host_sources[0], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
+            gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
+            GEO_HIP_CHECK(hipMemcpyAsync(ka.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            int32_t far = 0;
+            float amax = 0.f;
+            for (int32_t i = 0; i < n_sources; ++i)
+                if (std::isfinite(ka[i]) && ka[i] > amax) { amax = ka[i]; far = i; }
+            if (int rc = solve_single(indptr, indices, weights, n, host_sources[far], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
+            gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
+            GEO_HIP_CHECK(hipMemcpyAsync(kb.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            float bmax = 0.f;
+            for (int32_t i = 0; i < n_sources; ++i)
+                if (std::isfinite(kb[i]) && kb[i] > bmax) bmax = kb[i];
+            std::vector<uint64_t> key(n_sources);
+            for (int32_t i = 0; i < n_sources; ++i) {
+                // sources the landmarks cannot reach (other components) sort last
+                const uint32_t qa = std::isfinite(ka[i]) && amax > 0.f ? (uint32_t)(65535.0f * ka[i] / amax) : 65535u;
+                const uint32_t qb = std::isfinite(kb[i]) && bmax > 0.f ? (uint32_t)(65535.0f * kb[i] / bmax) : 65535u;
+                uint64_t m = 0;
+                for (int bit = 15; bit >= 0; --bit) m = (m << 2) | (uint64_t)(((qa >> bit) & 1u) << 1) | ((qb >> bit) & 1u);
+                key[i] = (m << 32) | (uint32_t)i;
+            }
+            std::sort(key.begin(), key.end());
+            for (int32_t i = 0; i < n_sources; ++i) order[i] = (int32_t)(key[i] & 0xffffffffu);
+            grouped = true;
         }
     }
+    const int32_t sweeps = total_sweeps;
     if (sweeps_out) *sweeps_out = sweeps;
     g_last_sweep_launches = sweeps;
     g_last_layout = sb + (chunked ? 1000 : 0);
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {
-        transpose_out_kernel<double, float><<<tgrid, 256, 0, stream>>>(w.dist, D_out, n, n_sources, sb);
+        transpose_out_kernel<double, float><<<tgrid, 256, 0, stream>>>(w.dist, D_out, n, n_sources, sb, row_of);
         GEO_LAUNCH_CHECK();
     }
     if (P_out) {
@@ -588,12 +724,12 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         else
             pred_multi_kernel<false><<<pg, 256, 0, stream>>>(indptr, indices, weights, n, nb, sb, w.dist, w.src_pad, w.pred);
         GEO_LAUNCH_CHECK();
-        transpose_out_kernel<int32_t, int32_t><<<tgrid, 256, 0, stream>>>(w.pred, P_out, n, n_sources, sb);
+        transpose_out_kernel<int32_t, int32_t><<<tgrid, 256, 0, stream>>>(w.pred, P_out, n, n_sources, sb, row_of);
         GEO_LAUNCH_CHECK();
     }
     if (dmin_out || argmin_out) {
         colmin_kernel<<<(unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), 256, 0, stream>>>(
-            w.dist, n, n_sources, sb, dmin_out, argmin_out);
+            w.dist, n, n_sources, sb, row_of, dmin_out, argmin_out);
         GEO_LAUNCH_CHECK();
     }
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
@@ -621,31 +757,8 @@ extern "C" int geo_sssp_single_update(const int32_t *indptr, const int32_t *indi
         return GEO_E_WORKSPACE;
     }
     const int grid1 = geo::grid_for(n, 256, 2048);
-    init_single_kernel<<<grid1, 256, 0, stream>>>(d, n, source, flags);
-    GEO_LAUNCH_CHECK();
-    const int grid = geo::grid_for(n, 16, 2048);      // 16 nodes per 256-thread block
-    int32_t sweeps = 0, hflag = 1;
-    const int64_t limit = (int64_t)n + 2;
-    while (hflag) {
-        int last_cur = 0;
-        for (int g = 0; g < SWEEP_GROUP; ++g, ++sweeps) {
-            const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
-            if (weights)
-                sweep_single_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
-                                                                    next, sweeps == 0);
-            else
-                sweep_single_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, d, flags, prev, cur,
-                                                                     next, sweeps == 0);
-            GEO_LAUNCH_CHECK();
-            last_cur = cur;
-        }
-        GEO_HIP_CHECK(hipMemcpyAsync(&hflag, flags + last_cur, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        GEO_HIP_CHECK(hipStreamSynchronize(stream));
-        if (hflag && sweeps > limit) {
-            geo::set_error("geo_sssp_single_update: no fixed point after %d sweeps", sweeps);
-            return GEO_E_NOCONV;
-        }
-    }
+    int32_t sweeps = 0;
+    if (int rc = solve_single(indptr, indices, weights, n, source, d, flags, SWEEP_GROUP, stream, &sweeps)) return rc;
     if (sweeps_out) *sweeps_out = sweeps;
     finish_single_kernel<<<grid1, 256, 0, stream>>>(d, n, d_out, dmin_inout, argmin_inout, center_pos);
     GEO_LAUNCH_CHECK();

@@ -133,30 +133,38 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
     it, it1 = 0, (K if absorb_last else K - 1)
     n_valid = K
-    # Solves: the first `warm` centres cross most of the graph and get twice the sweeps; afterwards the pruned
-    # cells are small.  A solve that needs more sweeps than were enqueued aborts harmlessly and is redone by
-    # the host-driven single-source solve.
-    sweeps, warm = int(os.environ.get("GEO_KPP_SWEEPS", "7")), 16
+    # Sweeps enqueued per solve: a solve exits early once converged, but every enqueued launch costs ~2 us, and a
+    # solve that needs more than were enqueued aborts and is redone.  The need is the hop radius of the new
+    # centre's (pruned) cell: the whole graph for the first centre, then shrinking.  So the chain runs in
+    # segments of doubling length; each takes its budget from what the previous one needed.
+    fixed = os.environ.get("GEO_KPP_SWEEPS")
+    budget, seg, cap = (int(fixed) if fixed else 16), 1, 4094
     finite = False
     status = np.zeros(4, dtype=np.int32)
     while it < it1:
-        seg_end, sw = (min(it1, warm), 2 * sweeps) if it < warm else (it1, sweeps)
+        seg_end = min(it1, it + seg)
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
                                          ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
-                                         K, sw, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
+                                         K, budget, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
                                          stream_ptr()),
                        "geo_kpp_chain")
-        t, reason = int(status[0]), int(status[1])
+        t, reason, used = int(status[0]), int(status[1]), int(status[3])
         finite = finite or int(status[2]) == 0          # inf entries only ever disappear from d_min
         if t < 0:
             chain.solves += seg_end - it
             it = seg_end
+            seg = min(2 * seg, 256)
+            if not fixed:
+                budget = min(cap, max(4, used + used // 8 + 1))     # cells shrink: the next segment needs no more
+            continue
+        if reason == 1 and budget < cap:                 # nothing of solve t was applied: redo it with more sweeps
+            chain.solves += t - it
+            budget, seg, it = min(cap, 4 * budget), 1, t
             continue
         chain.solves += t - it + 1
         centers_h = centers_d[: t + 1].cpu().numpy().astype(int).tolist()
-        if reason == 1:                                  # this solve needs more sweeps: host-driven solve
-            sweeps = min(2 * sweeps, 2048)
+        if reason == 1:                                  # beyond the device budget: host-driven solve
             chain.absorb(centers_h[t], t)
         if t + 1 >= K:
             break
