@@ -46,6 +46,17 @@ def clustered_latents(N, d, seed):
     return z
 
 
+def swiss_roll_latents(N, d, seed):
+    """Noisy 2-D swiss roll in d dims (SURVEY 8(d) second distribution; same generator as bench.swiss_roll)."""
+    r = np.random.RandomState(seed)
+    t = 1.5 * np.pi * (1.0 + 2.0 * r.rand(N))
+    h = 21.0 * r.rand(N)
+    x = np.zeros((N, d), dtype=np.float64)
+    x[:, 0], x[:, 1], x[:, 2] = t * np.cos(t), h, t * np.sin(t)
+    x = x / 7.0 + 0.02 * r.randn(N, d)
+    return x.astype(np.float32)
+
+
 def csr_from_golden(g, tag, n, with_data=True):
     from scipy import sparse
     ip, ix = g[f"{tag}/indptr"], g[f"{tag}/indices"]

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 from scipy import sparse
 
-from conftest import csr_from_golden, latents
+from conftest import csr_from_golden, latents, swiss_roll_latents
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +89,39 @@ def test_many_sources_vs_oracle(n_sources):
     W, _ = okn.build_knn_graph(latents(1500, 16, 7), k=8, mode="distance", sym="union")
     src = np.random.RandomState(n_sources).randint(0, 1500, size=n_sources)
     np.testing.assert_array_equal(dijkstra_multi_source(W, src), osp.dijkstra_multi_source(W, src))
+
+
+@pytest.mark.parametrize("group", ["0", "1", "2"])
+def test_long_geodesics_16_source_batches(group, monkeypatch):
+    """Manifold-like latents (noisy swiss roll, ~100-hop geodesics) at a size that takes the 16-source chunk
+    sweep, without / with automatic / with forced regrouping of the sources along landmark distances: distances,
+    predecessors, column minimum and first-row argmin (duplicate sources force ties) against the oracle."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    monkeypatch.setenv("GEO_SSSP_GROUP", group)
+    n = 14000
+    W, _ = okn.build_knn_graph(swiss_roll_latents(n, 16, 3), k=10, mode="distance", sym="union")
+    src = np.random.RandomState(5).choice(n, 70, replace=False)
+    src = np.concatenate([src, src[[3, 40, 69]]])                  # rows 70..72 repeat rows 3, 40, 69
+    Do, Po = osp.dijkstra_multi_source(W, src, return_predecessors=True)
+    D, P = dijkstra_multi_source(W, src, return_predecessors=True)
+    np.testing.assert_array_equal(D, Do)
+    reach = np.isfinite(Do)
+    # predecessors: same tree distances (ties between equal-length paths may pick another parent)
+    rows, cols = np.nonzero(reach & (P >= 0))
+    Wd = W.tocsr()
+    w_pv = np.asarray(Wd[P[rows, cols], cols]).ravel().astype(np.float64)
+    np.testing.assert_array_equal((P < 0), (Po < 0))
+    assert np.all(np.abs(Do[rows, P[rows, cols]].astype(np.float64) + w_pv - Do[rows, cols]) <= 1e-5 * (1 + Do[rows, cols]))
+    G = DeviceCSR.from_scipy(W, device())
+    _, _, dmin, arg, sweeps = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()),
+                                                want_D=False, want_min=True)
+    np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+    np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+    assert sweeps > 30                                              # long paths really were exercised
 
 
 def test_errors():

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
                                                            const uint32_t *__restrict__ bits_prev,
                                                            uint32_t *__restrict__ bits_cur, int32_t words, int prev,
                                                            int cur, int next, int first, int act_mode,
-                                                           int sparse_div, int map_div) {
+                                                           int sparse_div, int map_div, int c_pprev, int c_prev,
+                                                           int c_cur, int c_clear) {
     const int bid = blockIdx.x;
     if (bid == 0)
         for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
@@ -217,13 +218,20 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     // visiting only flagged rows pays when few rows moved (first sweeps, last sweeps): `counts` holds a
     // 1-in-16 block sample of the number of improved (node, source) pairs of the previous sweep
     // counts[.] >= 0: sampled count, map written;  < 0: -(sampled count), map NOT written by that sweep
-    const int32_t cp = first ? 0 : counts[prev * nb + b];
+    const int32_t cp = first ? 0 : counts[c_prev * nb + b];
+    const int32_t cpp = first ? 0 : counts[c_pprev * nb + b];
     const int32_t est_prev = (cp >= 0 ? cp : -cp) * 16;
-    const bool sparse_sweep = act_mode && (first || (cp >= 0 && (int64_t)est_prev * sparse_div < (int64_t)n * 16));
+    // expected improvements of THIS sweep: last sweep's count times its growth over the sweep before (a front
+    // that is still spreading multiplies by up to the mean degree per sweep; a converging solve shrinks)
+    const int32_t est_pprev = (cpp >= 0 ? cpp : -cpp) * 16;
+    float ratio = est_pprev > 0 ? (float)est_prev / (float)est_pprev : 32.0f;
+    ratio = ratio < 1.0f ? 1.0f : (ratio > 64.0f ? 64.0f : ratio);
+    const float expect = (float)est_prev * ratio;
+    const bool sparse_sweep = act_mode && (first || (cp >= 0 && expect * (float)sparse_div < (float)n * 16.0f));
     // flagging costs a scattered byte store per edge of every improved row: keep it only while few rows move
-    const bool write_map = sparse_sweep || (act_mode && (int64_t)est_prev * map_div < (int64_t)n * 16);
+    const bool write_map = sparse_sweep || (act_mode && expect * (float)map_div < (float)n * 16.0f);
     if (bid == 0)
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[next * nb + i] = 0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[c_clear * nb + i] = 0;
 
     const int lane = threadIdx.x & 63;
     const int slot_in_block = threadIdx.x >> 4;              // 16 slots of 16 lanes per block
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     for (int off = 32; off >= 1; off >>= 1) n_better += __shfl_xor(n_better, off, 64);
     if (lane == 0 && n_better > 0) {
         flags[cur * nb + b] = 1;                                          // exact: something changed
-        if ((xb & 15) == 0) atomicAdd(&counts[cur * nb + b], write_map ? n_better : -n_better);   // sampled: how much
+        if ((xb & 15) == 0) atomicAdd(&counts[c_cur * nb + b], write_map ? n_better : -n_better);   // sampled: how much
     }
 }
 
@@ -479,7 +487,7 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     const size_t words = ((size_t)n + 3) / 4;
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
-           geo::align_up(3 * (size_t)nb * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) + 256;
+           geo::align_up(4 * (size_t)nb * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) + 256;
 }
 
 size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
@@ -543,7 +551,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     int64_t n_chunks = 0;
     if (chunked) {
         bits = ar.take<uint32_t>(3 * (size_t)nb * words);
-        counts = ar.take<int32_t>(3 * (size_t)nb);
+        counts = ar.take<int32_t>(4 * (size_t)nb);
         int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
         const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
         chunk_node = ar.take<int32_t>(max_chunks);
@@ -567,7 +575,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     const int gs = nb < 8 ? nb : 8;
     const int groups = (nb + gs - 1) / gs;
     const int cap = 65536 / (gs * groups);
-    std::vector<int32_t> hflags(nb), hcounts(nb), order(n_sources), hsrc, host_sources(n_sources);
+    std::vector<int32_t> hflags(nb), hcounts(2 * (size_t)nb), order(n_sources), hsrc, host_sources(n_sources);
     for (int32_t i = 0; i < n_sources; ++i) order[i] = i;
     GEO_HIP_CHECK(hipMemcpyAsync(host_sources.data(), sources, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
@@ -594,7 +602,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
         GEO_LAUNCH_CHECK();
         if (chunked) {
-            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * (size_t)nb * 4, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 4 * (size_t)nb * 4, stream));
             GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb * words * 4, stream));
             source_need_kernel<<<geo::grid_for((int64_t)n_sources * 16, 256, 256), 256, 0, stream>>>(
                 w.src_pad, n_sources, n, sb, words, indptr, indices, bits + 2 * (size_t)nb * words);
@@ -628,18 +636,20 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                     if (weights)
                         sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                              (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                             counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv);
+                                                                             counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv,
+                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4);
                     else
                         sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                               (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
-                                                                              counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv);
+                                                                              counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv,
+                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4);
                 } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
                 else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
                 GEO_LAUNCH_CHECK();
                 if (chunked && getenv("GEO_SSSP_TRACE")) {            // experiment: sampled improvement counts per sweep
                     std::vector<int32_t> hc(nb);
-                    GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)cur * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));
+                    GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)(sweeps % 4) * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));
                     long long tot = 0, neg = 0;
                     for (int32_t b = 0; b < nb; ++b) { tot += hc[b] < 0 ? -hc[b] : hc[b]; neg += hc[b] < 0; }
                     fprintf(stderr, "[sssp] sweep %d: ~%lld improved pairs (%.1f%% of pairs), %lld/%d batches without map\n", sweeps,
@@ -650,9 +660,13 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
             GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
             GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
                                          hipMemcpyDeviceToHost, stream));
-            if (chunked)
-                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data(), counts + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
+            if (chunked) {                       // improvement counts of the last two sweeps (4-slot ring)
+                const int c_last = (sweeps + 3) % 4, c_before = (sweeps + 2) % 4;        // `sweeps` already counts them
+                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data(), counts + (size_t)c_last * nb, (size_t)nb * sizeof(int32_t),
                                              hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data() + nb, counts + (size_t)c_before * nb, (size_t)nb * sizeof(int32_t),
+                                             hipMemcpyDeviceToHost, stream));
+            }
             GEO_HIP_CHECK(hipStreamSynchronize(stream));
             float ms = 0.f;
             GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
@@ -664,9 +678,9 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                 return GEO_E_NOCONV;
             }
             if (!done && chunked && !grouped && group_mode != 0 && attempt == 0 && sweeps == SWEEP_GROUP) {
-                // after the first sweeps: how much of the (node, source) matrix moved in the last one?
+                // after the first sweeps: how much of the (node, source) matrix moved in the last two?
                 double moved = 0.0;
-                for (int32_t b = 0; b < nb; ++b) moved += 16.0 * (hcounts[b] < 0 ? -hcounts[b] : hcounts[b]);
+                for (int32_t b = 0; b < 2 * nb; ++b) moved += 16.0 * (hcounts[b] < 0 ? -hcounts[b] : hcounts[b]);
                 regroup = group_mode == 2 || moved < 0.25 * (double)nb * n * 16;
             }
             if (sweeps >= 16 && group_len < 16) group_len *= 2;      // long solves: fewer host round trips
