@@ -117,20 +117,50 @@ def test_generic_decoder_properties_on_gpu():
                           edge_lengths_riemannian(dec, zi, zj, batch_size=1024), rtol=1e-5, atol=1e-7)
 
 
-def test_groupnorm_decoder_takes_the_autograd_path(golden):
-    """GroupNorm is outside the kernels' coverage: the drop-in still answers (autograd on the GPU, the
-    reference's own method) and matches the reference's golden lengths."""
+def _group_decoder(channels, seed=12):
     from oracle import metric as om
-    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
-    from vqvae_amd.spatial_decoder import SpatialDecoder, hip_kernels_cover
-    sd = om.make_decoder_state(12, 16, 1, norm_type="group")
-    dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "group")
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    sd = om.make_decoder_state(seed, 16, 1, channels=channels, norm_type="group")
+    dec = SpatialDecoder(1, channels, 16, 28, "group")
     dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    assert not hip_kernels_cover(dec)
     r = np.random.RandomState(112)
     zs = r.randn(E, 16).astype(np.float32)
     ze = (zs + 0.3 * r.randn(E, 16)).astype(np.float32)
+    return dec, sd, zs, ze
+
+
+@pytest.mark.parametrize("bs", [512, 100])
+def test_groupnorm_decoder_on_the_hip_path(golden, bs):
+    """GroupNorm (32 groups per layer, the reference's default 256-128-64 decoder) runs in csrc/jvp.hip: per-sample
+    group statistics are independent of the chunking and of train/eval mode."""
+    from oracle import metric as om
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    from vqvae_amd.spatial_decoder import hip_kernels_cover
+    dec, sd, zs, ze = _group_decoder((256, 128, 64))
+    assert hip_kernels_cover(dec)
+    L = edge_lengths_riemannian(dec.cuda().eval(), torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs)
+    assert L.is_cuda and L.shape == (E,)
+    L = L.cpu().numpy()
+    ref = golden("metric")["fm_group/train0/bs512"]
+    rel = np.abs(L[:len(ref)] - ref) / ref
+    assert np.mean(rel <= TOL) >= 0.999, (rel.max(), np.quantile(rel, 0.999))
+    L64 = om.edge_lengths(sd, "group", 28, zs, ze, batch_size=512, training=False, dtype=torch.float64).numpy()
+    rel64 = np.abs(L - L64) / np.abs(L64)
+    assert np.mean(rel64 <= TOL) >= 0.999, (rel64.max(), np.quantile(rel64, 0.999))
+    assert np.quantile(rel64, 0.99) < 2e-6
+    Lt = edge_lengths_riemannian(dec.train(), torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs).cpu().numpy()
+    np.testing.assert_array_equal(L, Lt)
+
+
+def test_groupnorm_decoder_outside_the_kernels_takes_the_autograd_path():
+    """A GroupNorm decoder whose layout the kernels do not cover (dec_channels[2] != 64): the drop-in still answers
+    (autograd on the GPU, the reference's own method) and agrees with the fp64 closed form."""
+    from oracle import metric as om
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    from vqvae_amd.spatial_decoder import hip_kernels_cover
+    dec, sd, zs, ze = _group_decoder((64, 32, 16))
+    assert not hip_kernels_cover(dec)
     L = edge_lengths_riemannian(dec.cuda().eval(), torch.from_numpy(zs[:512]), torch.from_numpy(ze[:512]), batch_size=512)
-    ref = golden("metric")["fm_group/train0/bs512"][:512]
-    rel = np.abs(L.cpu().numpy() - ref) / ref
-    assert L.is_cuda and np.mean(rel <= 1e-5) >= 0.99
+    L64 = om.edge_lengths(sd, "group", 28, zs[:512], ze[:512], batch_size=512, training=False, dtype=torch.float64).numpy()
+    rel = np.abs(L.cpu().numpy() - L64) / L64
+    assert L.is_cuda and np.mean(rel <= 1e-4) >= 0.99

@@ -215,6 +215,8 @@ __global__ void finalize_fixed_kernel(int C, int norm, const float *__restrict__
         if (norm == 1) {
             const double inv = 1.0 / sqrt((double)rv[c] + (double)eps);
             k.mu = rm[c]; k.sc = (float)(inv * gamma[c]); k.beta = beta[c];
+        } else if (norm == 2) {                               // GroupNorm: per-channel affine only, statistics per sample
+            k.mu = 0.f; k.sc = gamma[c]; k.beta = beta[c];
         } else {
             k.mu = 0.f; k.sc = 1.f; k.beta = 0.f;
         }
@@ -229,6 +231,46 @@ __device__ __forceinline__ void norm_relu(const NormConst &k, float x, float t, 
     const float tt = k.sc * (t - k.mt - xc * k.c5);
     *a = y > 0.f ? y : 0.f;
     *ta = y > 0.f ? tt : 0.f;
+}
+
+// GroupNorm (spatial_vae.py:13-16): statistics per (sample, group) over the group's channels and all pixels.
+// g = {mean, 1/sqrt(var+eps), mean(t), inv * mean(xhat * t)}; gamma/beta per channel.
+__device__ __forceinline__ void norm_relu_gn(const float4 &g, float gamma, float beta, float x, float t, float *a,
+                                             float *ta) {
+    const float xc = x - g.x;
+    const float sc = g.y * gamma;
+    const float y = fmaf(xc, sc, beta);
+    const float tt = sc * (t - g.z - xc * g.w);
+    *a = y > 0.f ? y : 0.f;
+    *ta = y > 0.f ? tt : 0.f;
+}
+
+// pre / tpre: [slot][npx][C]; out: [slot][G].  fp64 accumulation, rounded once.
+__global__ __launch_bounds__(256) void group_stats_kernel(const float *__restrict__ pre, const float *__restrict__ tpre,
+                                                         int64_t n_slots, int npx, int C, int G, float eps,
+                                                         float4 *__restrict__ out) {
+    const int cpg = C / G;
+    const int64_t total = n_slots * G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const int64_t slot = i / G;
+        const float *x = pre + (size_t)slot * npx * C + (size_t)g * cpg;
+        const float *t = tpre + (size_t)slot * npx * C + (size_t)g * cpg;
+        double sx = 0.0, sxx = 0.0, st = 0.0, sxt = 0.0;
+        for (int px = 0; px < npx; ++px)
+            for (int k = 0; k < cpg; ++k) {
+                const double xv = (double)x[(size_t)px * C + k], tv = (double)t[(size_t)px * C + k];
+                sx += xv; sxx += xv * xv; st += tv; sxt += xv * tv;
+            }
+        const double n = (double)npx * cpg;
+        const double mu = sx / n;
+        double var = sxx / n - mu * mu;
+        if (var < 0) var = 0;
+        const double inv = 1.0 / sqrt(var + (double)eps);
+        const double mt = st / n;
+        const double mxt = (sxt - mu * st) * inv / n;
+        out[i] = make_float4((float)mu, (float)inv, (float)mt, (float)(inv * mxt));
+    }
 }
 
 // ---------------------------------------------------------------------------------- mid (MFMA)
@@ -456,14 +498,15 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
 // {1,2,5,6} (10 of the 20 (pixel, chunk) products each, 2 or 3 per pixel): 4 x 2 accumulator tiles = 128
 // registers per wave, so two waves share a SIMD and one's weight-fragment loads (L2) hide behind the other's
 // MFMAs.
-template <int C1>
+template <int C1, bool GN>
 __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
                                                         const NormConst *__restrict__ consts1, int consts_per_group,
                                                         int tiles_per_group, ChunkTable tab, int c2,
                                                         const unsigned short *__restrict__ B3,
                                                         const float *__restrict__ b2, float *__restrict__ pre2,
                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
-                                                        int want_stats, const int32_t *__restrict__ slot_valid) {
+                                                        int want_stats, const int32_t *__restrict__ slot_valid,
+                                                        const float4 *__restrict__ gs1) {
     constexpr int LDK = C1 + 8;
     constexpr int KS = C1 / 16;
     constexpr int NL = 4;                                      // chunks per wave group
@@ -494,6 +537,12 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
 #pragma unroll
         for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
     }
+    // GroupNorm (32 groups): the thread's CPT = C1/16 channels span exactly two groups of C1/32 channels
+    float4 gg0 = make_float4(0.f, 0.f, 0.f, 0.f), gg1 = gg0;
+    if (GN) {
+        gg0 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2];
+        gg1 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2 + 1];
+    }
     __syncthreads();                                           // kc visible
     for (int ip = 0; ip < 4; ++ip) {
         const int buf = ip & 1;
@@ -502,7 +551,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 float a, ta;
-                norm_relu(kc[k0 + k], rawp[k], rawt[k], &a, &ta);
+                if (GN) norm_relu_gn(k < CPT / 2 ? gg0 : gg1, kc[k0 + k].sc, kc[k0 + k].beta, rawp[k], rawt[k], &a, &ta);
+                else norm_relu(kc[k0 + k], rawp[k], rawt[k], &a, &ta);
                 split3(a, pp[0][k], pp[1][k], pp[2][k]);
                 split3(ta, pt[0][k], pt[1][k], pt[2][k]);
             }
@@ -713,16 +763,20 @@ __global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict_
                                                        const NormConst *__restrict__ consts2, int consts_per_group,
                                                        int tiles_per_group, int co_n, int s_out,
                                                        const unsigned short *__restrict__ W3b,
-                                                       const float *__restrict__ b3, float *__restrict__ norms) {
+                                                       const float *__restrict__ b3, float *__restrict__ norms,
+                                                       const float4 *__restrict__ gs2) {
     constexpr int C2 = 64, KB = 128, LDK = KB + 8, NP = NT * 32;
     __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];     // 52 KB, reused for the reduction
     __shared__ NormConst kc[C2];
+    __shared__ float4 gsl[TS][32];                                                // GroupNorm: per (sample, group)
     const int tile = blockIdx.x;
     const int group = tile / tiles_per_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n2 = 16 * C2, P = co_n * s_out * s_out;
     const size_t slot0 = (size_t)tile * TS;
     for (int c = threadIdx.x; c < C2; c += 256) kc[c] = consts2[(size_t)(consts_per_group ? group : 0) * C2 + c];
+    if (gs2)
+        for (int i = threadIdx.x; i < TS * 32; i += 256) gsl[i >> 5][i & 31] = gs2[slot0 * 32 + i];
 
     f32x16 accp[NT], acct[NT];
 #pragma unroll
@@ -743,7 +797,9 @@ __global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict_
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float a, ta;
-                    norm_relu(kc[(k0 + k8 + k) & (C2 - 1)], xp[k8 + k], xt[k8 + k], &a, &ta);
+                    const int c = (k0 + k8 + k) & (C2 - 1);
+                    if (gs2) norm_relu_gn(gsl[ss][c >> 1], kc[c].sc, kc[c].beta, xp[k8 + k], xt[k8 + k], &a, &ta);
+                    else norm_relu(kc[c], xp[k8 + k], xt[k8 + k], &a, &ta);
                     unsigned short q1, q2, q3;
                     split3(a, q1, q2, q3);
                     pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3;
@@ -902,6 +958,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += geo::align_up(tiles * s.n1 * 4 * 8) + geo::align_up(tiles * s.n2 * 4 * 8);         // partial sums
     b += geo::align_up((groups + 1) * s.c1 * sizeof(NormConst)) + geo::align_up((groups + 1) * s.c2 * sizeof(NormConst));
     b += geo::align_up(slots * 4) * 2;                                                      // norms, slot_valid
+    if (dc->norm == 2) b += 2 * geo::align_up(slots * 32 * sizeof(float4));                 // GroupNorm statistics
     p->bytes = b + 4096;
     return true;
 }
@@ -918,7 +975,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     const Shape &s = pl.sh;
     GEO_REQUIRE(s.d >= 1 && s.d <= 64, "geo_decoder_jvp: latent_dim %d not in [1,64]", s.d);
     GEO_REQUIRE(s.c1 == 128 || s.c1 == 64 || s.c1 == 32, "geo_decoder_jvp: dec_channels[1]=%d not in {32,64,128}", s.c1);
-    GEO_REQUIRE(dc->norm == 0 || dc->norm == 1, "geo_decoder_jvp: norm_type 'group' is not implemented in the HIP path");
+    GEO_REQUIRE(dc->norm >= 0 && dc->norm <= 2, "geo_decoder_jvp: unknown norm code %d", dc->norm);
     GEO_REQUIRE(s.c2 % 16 == 0, "geo_decoder_jvp: dec_channels[2]=%d must be a multiple of 16", s.c2);
     const size_t back_lds = ((size_t)2 * BACK_TS * 16 * (s.c2 + 4) + (size_t)16 * s.co * (s.c2 + 4) +
                              (size_t)BACK_TS * s.p_out) * 4;
@@ -942,6 +999,12 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     NormConst *k1 = ar.take<NormConst>((groups + 1) * s.c1), *k2 = ar.take<NormConst>((groups + 1) * s.c2);
     float *norms = ar.take<float>(slots);
     int32_t *slot_valid = ar.take<int32_t>(slots);
+    float4 *gs1 = nullptr, *gs2 = nullptr;
+    if (dc->norm == 2) {
+        gs1 = ar.take<float4>(slots * 32);
+        gs2 = ar.take<float4>(slots * 32);
+        GEO_REQUIRE(gs2 != nullptr, "geo_decoder_jvp: workspace carve failed");
+    }
     GEO_REQUIRE(slot_valid != nullptr, "geo_decoder_jvp: workspace carve failed");
 
     ChunkTable tab;
@@ -970,6 +1033,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_LAUNCH_CHECK();
     }
 
+    if (dc->norm == 2) {
+        // the GroupNorm path exists for the 32-group layouts of the matrix-core kernels (reference default decoder)
+        GEO_REQUIRE(dc->groups1 == 32 && dc->groups2 == 32 && s.c2 == 64 && back_mfma && mid_split && s.n_chunks == 8 &&
+                        s.opix_per_chunk == 2 && !(mid_env && mid_env[0] == 'c'),
+                    "geo_decoder_jvp: GroupNorm needs 32 groups per layer and dec_channels[2] == 64 (got %d/%d groups, c2=%d)",
+                    dc->groups1, dc->groups2, s.c2);
+    }
     const bool batch_stats = dc->norm == 1 && dc->bn_train;
     if (!batch_stats) {
         finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c1, dc->norm, dc->g1, dc->be1, dc->rm1, dc->rv1, dc->eps, k1);
@@ -1002,6 +1072,11 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                 part1, pl.tiles_per_group, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups);
             GEO_LAUNCH_CHECK();
         }
+        if (gs1) {
+            group_stats_kernel<<<geo::grid_for(p_slots * 32, 256), 256, 0, stream>>>(pre1, tpre1, p_slots, 4, s.c1, 32,
+                                                                                    dc->eps, gs1);
+            GEO_LAUNCH_CHECK();
+        }
         const dim3 mgrid((unsigned)p_tiles, (unsigned)s.n_chunks);
 #define GEO_MID(C1V)                                                                                               \
     mid_kernel<C1V><<<mgrid, 256, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, tab,       \
@@ -1014,13 +1089,18 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
                              !(mid_env && mid_env[0] == 'c');
         if (mid_all) {
-#define GEO_MIDA(C1V)                                                                                              \
-    mid_all_kernel<C1V><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,                \
-                                                               pl.tiles_per_group, tab, s.c2, B3, dc->b2, pre2,     \
-                                                               tpre2, part2, batch_stats ? 1 : 0, slot_valid)
-            if (s.c1 == 128) GEO_MIDA(128);
-            else if (s.c1 == 64) GEO_MIDA(64);
-            else GEO_MIDA(32);
+#define GEO_MIDA(C1V, GNV)                                                                                         \
+    mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
+                                                                    pl.tiles_per_group, tab, s.c2, B3, dc->b2,      \
+                                                                    pre2, tpre2, part2, batch_stats ? 1 : 0,        \
+                                                                    slot_valid, gs1)
+            if (gs1) {
+                if (s.c1 == 128) GEO_MIDA(128, true);
+                else if (s.c1 == 64) GEO_MIDA(64, true);
+                else GEO_MIDA(32, true);
+            } else if (s.c1 == 128) GEO_MIDA(128, false);
+            else if (s.c1 == 64) GEO_MIDA(64, false);
+            else GEO_MIDA(32, false);
 #undef GEO_MIDA
         } else if (mid_split) {
             if (s.c1 == 128) GEO_MID3(128);
@@ -1039,12 +1119,17 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                 part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups);
             GEO_LAUNCH_CHECK();
         }
+        if (gs2) {
+            group_stats_kernel<<<geo::grid_for(p_slots * 32, 256), 256, 0, stream>>>(pre2, tpre2, p_slots, 16, s.c2, 32,
+                                                                                    dc->eps, gs2);
+            GEO_LAUNCH_CHECK();
+        }
         if (back_mfma && back_nt == 1)
             back_mfma_kernel<1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
-                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms);
+                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms, gs2);
         else if (back_mfma)
             back_mfma_kernel<6><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
-                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms);
+                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms, gs2);
         else
             back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
                 pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);

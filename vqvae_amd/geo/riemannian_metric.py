@@ -6,7 +6,8 @@ kernels of csrc/jvp.hip (forward-mode tangent propagation, MFMA for the dominant
 chunked by `batch_size` exactly like riemannian_metric.py:50-58 so that train-mode BatchNorm sees
 the same batches.  Any other nn.Module (e.g. the Linear test decoder of the reference's
 tests/test_riemannian_metric.py, the vanilla VAE decoder, or a SpatialDecoder variant outside the kernels'
-coverage such as GroupNorm) has no kernel: it is differentiated by autograd on the decoder's own device.
+coverage, see spatial_decoder.hip_kernels_cover) has no kernel: it is differentiated by autograd on the
+decoder's own device.  BatchNorm (train and eval), GroupNorm and no normalisation are all in the kernels.
 """
 import torch
 

@@ -84,12 +84,14 @@ def looks_like_spatial_decoder(m: nn.Module) -> bool:
 
 def hip_kernels_cover(m: nn.Module) -> bool:
     """Whether csrc/jvp.hip implements this SpatialDecoder-shaped module (else the caller differentiates it
-    with autograd): BatchNorm or no norm, dec_channels[1] in {32,64,128}, dec_channels[2] a multiple of 16
-    dividing 128, latent_dim <= 64, LDS budget of the output stage."""
+    with autograd): dec_channels[1] in {32,64,128}, dec_channels[2] a multiple of 16 dividing 128,
+    latent_dim <= 64, LDS budget of the output stage; GroupNorm with 32 groups per layer and
+    dec_channels[2] == 64 (the reference's default decoder 256-128-64)."""
     seq = m.deconv_layers
-    if isinstance(seq[1], nn.GroupNorm):
-        return False
     d, c1, c2, co = m.conv_in.in_channels, seq[0].out_channels, seq[3].out_channels, seq[6].out_channels
+    if isinstance(seq[1], nn.GroupNorm):
+        if seq[1].num_groups != 32 or seq[4].num_groups != 32 or c2 != 64:
+            return False
     s_out = 8 if seq[6].padding[0] == 1 else 4
     back_lds = (2 * 8 * 16 * (c2 + 4) + 16 * co * (c2 + 4) + 8 * co * s_out * s_out) * 4
     return (d <= 64 and c1 in (32, 64, 128) and c2 % 16 == 0 and 128 % c2 == 0 and back_lds <= 160 * 1024
@@ -136,6 +138,10 @@ class DecoderExport:
         elif isinstance(norm, nn.GroupNorm):
             d.norm, d.eps, d.bn_train = 2, norm.eps, 0
             d.groups1, d.groups2 = seq[1].num_groups, seq[4].num_groups
+            if norm.weight is None:                      # affine=False
+                for t, c in (("1", d.c1), ("2", d.c2)):
+                    self.tensors["g" + t] = torch.ones(c, device=dev)
+                    self.tensors["be" + t] = torch.zeros(c, device=dev)
         else:
             d.norm, d.eps, d.bn_train = 0, 1e-5, 0
         for name, t in self.tensors.items():
