@@ -79,11 +79,12 @@ int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const 
  * (float32 D^2 weights, float32 add.reduce, fp64 cdf, searchsorted) from the uniform deviate u_host[t]
  * the caller took from the same RandomState stream.  centers i32 [n_centers_total] (centers[it0] set by
  * the caller), is_center u8 [n] (set for centers[0..it0]), dmin f32 [n] / argmin i32 [n] carried state.
- * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged).
+ * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged); 0 (needs
+ * assume_finite) runs the chain as one step kernel launched until done: no budget, reason 1 only past 4094 sweeps.
  * assume_finite != 0 promises that d_min has no inf entry left (status_out[2] of an earlier call): the
  * per-iteration maximum pass is skipped.
  * status_out [host, 4 ints]: {abort_iter or -1, reason, inf entries of d_min at the last maximum pass,
- * most sweeps any solve of this call needed}:
+ * most sweeps any solve of this call needed (step kernel: launches that did work)}:
  * reason 1 = solve not converged (nothing of that iteration is applied), 2 = u too close to a cdf boundary,
  * 3 = degenerate weights (for 2 and 3 the solve of that iteration IS applied, the draw is not).  The caller
  * repeats that step another way and resumes.

@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void pack_back_bf16_kernel(const float *__rest
     }
 }
 
-template <int NT>
+template <int NT, bool GN>
 __global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
                                                        const NormConst *__restrict__ consts2, int consts_per_group,
                                                        int tiles_per_group, int co_n, int s_out,
@@ -768,14 +768,14 @@ __global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict_
     constexpr int C2 = 64, KB = 128, LDK = KB + 8, NP = NT * 32;
     __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];     // 52 KB, reused for the reduction
     __shared__ NormConst kc[C2];
-    __shared__ float4 gsl[TS][32];                                                // GroupNorm: per (sample, group)
+    __shared__ float4 gsl[GN ? TS : 1][32];                                       // GroupNorm: per (sample, group)
     const int tile = blockIdx.x;
     const int group = tile / tiles_per_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n2 = 16 * C2, P = co_n * s_out * s_out;
     const size_t slot0 = (size_t)tile * TS;
     for (int c = threadIdx.x; c < C2; c += 256) kc[c] = consts2[(size_t)(consts_per_group ? group : 0) * C2 + c];
-    if (gs2)
+    if (GN)
         for (int i = threadIdx.x; i < TS * 32; i += 256) gsl[i >> 5][i & 31] = gs2[slot0 * 32 + i];
 
     f32x16 accp[NT], acct[NT];
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict_
                 for (int k = 0; k < 8; ++k) {
                     float a, ta;
                     const int c = (k0 + k8 + k) & (C2 - 1);
-                    if (gs2) norm_relu_gn(gsl[ss][c >> 1], kc[c].sc, kc[c].beta, xp[k8 + k], xt[k8 + k], &a, &ta);
+                    if (GN) norm_relu_gn(gsl[GN ? ss : 0][c >> 1], kc[c].sc, kc[c].beta, xp[k8 + k], xt[k8 + k], &a, &ta);
                     else norm_relu(kc[c], xp[k8 + k], xt[k8 + k], &a, &ta);
                     unsigned short q1, q2, q3;
                     split3(a, q1, q2, q3);
@@ -1124,12 +1124,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                                                                                     dc->eps, gs2);
             GEO_LAUNCH_CHECK();
         }
-        if (back_mfma && back_nt == 1)
-            back_mfma_kernel<1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
-                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms, gs2);
-        else if (back_mfma)
-            back_mfma_kernel<6><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,
-                                                                      pl.tiles_per_group, s.co, s.s_out, W3b, dc->b3, norms, gs2);
+#define GEO_BACK(NTV, GNV)                                                                                         \
+    back_mfma_kernel<NTV, GNV><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,         \
+                                                                      pl.tiles_per_group, s.co, s.s_out, W3b,       \
+                                                                      dc->b3, norms, gs2)
+        if (back_mfma && back_nt == 1) { if (gs2) GEO_BACK(1, true); else GEO_BACK(1, false); }
+        else if (back_mfma) { if (gs2) GEO_BACK(6, true); else GEO_BACK(6, false); }
+#undef GEO_BACK
         else
             back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
                 pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);

@@ -74,22 +74,15 @@ __global__ void kpp_begin_kernel(KppCtl *ctl, const int32_t *__restrict__ center
 // lowers its neighbours with a 64-bit atomicMin on the bit pattern; lowered, unpruned neighbours are queued
 // once for the next sweep.  The queue tail is advanced once per wave (ballot), not once per node.
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
-                                                      const int32_t *__restrict__ indices,
-                                                      const float *__restrict__ weights, double *d,
-                                                      const float *__restrict__ dmin, int32_t *mark,
-                                                      const int32_t *__restrict__ fin, int32_t *__restrict__ fout,
-                                                      int cur, int next, int clear, int32_t stamp_solve, int32_t sw) {
-    if (ctl->abort_iter >= 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
-    const int32_t cnt = ctl->fcount[cur];
-    if (cnt == 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && sw + 1 > ctl->max_sw) ctl->max_sw = sw + 1;   // launches are serial
+__device__ __forceinline__ void kpp_push_body(KppCtl *ctl, const int32_t *__restrict__ indptr,
+                                              const int32_t *__restrict__ indices, const float *__restrict__ weights,
+                                              double *d, const float *__restrict__ dmin, int32_t *mark,
+                                              const int32_t *__restrict__ fin, int32_t *__restrict__ fout, int32_t cnt,
+                                              int next, int32_t stamp) {
     const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
     const int sub = threadIdx.x & 31, lane = threadIdx.x & 63;       // 32 lanes per frontier node (mean degree ~31)
     const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int ngrp = (gridDim.x * blockDim.x) >> 5;
-    const int32_t stamp = stamp_solve * 4096 + sw + 1;
     unsigned long long *dbits = reinterpret_cast<unsigned long long *>(d);
     for (int32_t i = grp; i < cnt; i += ngrp) {
         const int32_t u = fin[i];
@@ -115,6 +108,22 @@ __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_
             }
         }
     }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ weights, double *d,
+                                                      const float *__restrict__ dmin, int32_t *mark,
+                                                      const int32_t *__restrict__ fin, int32_t *__restrict__ fout,
+                                                      int cur, int next, int clear, int32_t stamp_solve, int32_t sw) {
+    if (ctl->abort_iter >= 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
+    const int32_t cnt = ctl->fcount[cur];
+    if (cnt == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sw + 1 > ctl->max_sw) ctl->max_sw = sw + 1;   // launches are serial
+    kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, fin, fout, cnt, next,
+                            stamp_solve * 4096 + sw + 1);
 }
 
 // d_min / argmin update (kmeans_optimized.py:44 + the single-pass assignment) outside the fused path below;
@@ -190,12 +199,12 @@ template <typename T>
 __device__ __forceinline__ T ld_dev(const T *p) {
     return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool last_block_done(int32_t *ticket) {
+__device__ __forceinline__ bool last_block_done(int32_t *ticket, int32_t participants) {
     __shared__ int32_t s_last;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0)
-        s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1) ? 1 : 0;
+        s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == participants - 1) ? 1 : 0;
     __syncthreads();
     return s_last != 0;
 }
@@ -211,28 +220,25 @@ __device__ __forceinline__ bool last_block_done(int32_t *ticket) {
 // `exact_max`: the per-block maxima of kpp_max_kernel are reduced here (needed when d_min still holds inf
 // entries, which are replaced by 2*max_finite); otherwise every entry is finite and no maximum is needed.
 constexpr int SUM_LEAVES = 32, TREE_LDS_NODES = 1024;
-__global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__restrict__ dmin,
-                                                     int32_t *__restrict__ argmin, double *__restrict__ d,
-                                                     int fuse_finish, int last_next, int32_t pos,
-                                                     const uint8_t *__restrict__ is_center,
-                                                     const float *__restrict__ part_max,
-                                                     const int32_t *__restrict__ part_inf, int n_part, int exact_max,
-                                                     float *__restrict__ probs,
-                                                     const int32_t *__restrict__ leaf_start,
-                                                     const int32_t *__restrict__ leaf_len, int n_leaves,
-                                                     const int32_t *__restrict__ node_l,
-                                                     const int32_t *__restrict__ node_r,
-                                                     const int32_t *__restrict__ level_off, int n_levels,
-                                                     const int32_t *__restrict__ chunk_root, int n_chunks,
-                                                     float *val) {
-    if (ctl->abort_iter >= 0) return;
-    if (fuse_finish && ctl->fcount[last_next] != 0) {          // the solve did not converge: apply nothing
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
-        return;
-    }
+struct SumPlan {                          // numpy's reduction tree over n float32 (host-built, see pw_build)
+    const int32_t *leaf_start, *leaf_len, *node_l, *node_r, *level_off, *chunk_root;
+    int n_leaves, n_levels, n_chunks;
+    float *val;
+};
+
+// Block `bid` of `nblocks`.  Returns true (for all its threads) in the block that finished the tree; its thread 0
+// then holds the total in *total_out.
+__device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dmin, int32_t *__restrict__ argmin,
+                                             double *__restrict__ d, int fuse_finish, int32_t pos,
+                                             const uint8_t *__restrict__ is_center, const float *__restrict__ part_max,
+                                             const int32_t *__restrict__ part_inf, int n_part, int exact_max,
+                                             float *__restrict__ probs, const SumPlan &pl, int bid, int nblocks,
+                                             float *total_out) {
     __shared__ float sp[SUM_LEAVES * PW_BLOCK];
     __shared__ float smax;
     __shared__ int32_t sinf;
+    const int n_leaves = pl.n_leaves;
+    float *val = pl.val;
     float maxf = 0.0f;
     bool any_finite = true;
     if (exact_max) {
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
         __syncthreads();
         maxf = smax;
         any_finite = maxf >= 0.0f;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->maxf = maxf; ctl->n_inf = sinf; }   // margin of the next solve
+        if (bid == 0 && threadIdx.x == 0) { ctl->maxf = maxf; ctl->n_inf = sinf; }   // margin of the next solve
     }
     const float sub = maxf * 2.0f;
-    const int l0 = blockIdx.x * SUM_LEAVES;
+    const int l0 = bid * SUM_LEAVES;
     const int l1 = l0 + SUM_LEAVES < n_leaves ? l0 + SUM_LEAVES : n_leaves;
-    const int32_t b0 = leaf_start[l0], b1 = leaf_start[l1 - 1] + leaf_len[l1 - 1];
+    const int32_t b0 = pl.leaf_start[l0], b1 = pl.leaf_start[l1 - 1] + pl.leaf_len[l1 - 1];
     for (int32_t i = b0 + threadIdx.x; i < b1; i += 256) {
         float x = dmin[i];
         if (fuse_finish) {
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
         const int j = threadIdx.x & 7;
         const int leaf = l0 + (threadIdx.x >> 3);
         const bool live = leaf < l1;
-        const float *a = sp + (live ? leaf_start[leaf] - b0 : 0);
-        const int len = live ? leaf_len[leaf] : 0;
+        const float *a = sp + (live ? pl.leaf_start[leaf] - b0 : 0);
+        const int len = live ? pl.leaf_len[leaf] : 0;
         const int m8 = len - (len % 8);
         float r = 0.0f;
         if (len >= 8) {
@@ -301,16 +307,17 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
             if (live) st_dev(&val[leaf], r);
         }
     }
-    if (!last_block_done(&ctl->ticket[0])) return;
+    if (!last_block_done(&ctl->ticket[0], nblocks)) return false;
     __shared__ int32_t s_nl[TREE_LDS_NODES], s_nr[TREE_LDS_NODES], s_lo[32], s_cr[64];
-    const int n_nodes = level_off[n_levels];
+    const int n_levels = pl.n_levels, n_chunks = pl.n_chunks;
+    const int n_nodes = pl.level_off[n_levels];
     float total = 0.0f;
     if (n_nodes <= TREE_LDS_NODES && n_leaves + n_nodes <= SUM_LEAVES * PW_BLOCK && n_levels < 32 && n_chunks <= 64) {
         // small tree: one round trip brings leaves and plan into LDS, the levels then cost LDS latency only
         for (int j = threadIdx.x; j < n_leaves; j += 256) sp[j] = ld_dev(&val[j]);
-        for (int j = threadIdx.x; j < n_nodes; j += 256) { s_nl[j] = node_l[j]; s_nr[j] = node_r[j]; }
-        if (threadIdx.x <= n_levels) s_lo[threadIdx.x] = level_off[threadIdx.x];
-        if (threadIdx.x < n_chunks) s_cr[threadIdx.x] = chunk_root[threadIdx.x];
+        for (int j = threadIdx.x; j < n_nodes; j += 256) { s_nl[j] = pl.node_l[j]; s_nr[j] = pl.node_r[j]; }
+        if (threadIdx.x <= n_levels) s_lo[threadIdx.x] = pl.level_off[threadIdx.x];
+        if (threadIdx.x < n_chunks) s_cr[threadIdx.x] = pl.chunk_root[threadIdx.x];
         __syncthreads();
         for (int lv = 0; lv < n_levels; ++lv) {
             for (int j = s_lo[lv] + threadIdx.x; j < s_lo[lv + 1]; j += 256) sp[n_leaves + j] = sp[s_nl[j]] + sp[s_nr[j]];
@@ -320,14 +327,34 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
             for (int c = 0; c < n_chunks; ++c) total += sp[s_cr[c]];
     } else {
         for (int lv = 0; lv < n_levels; ++lv) {
-            for (int j = level_off[lv] + threadIdx.x; j < level_off[lv + 1]; j += blockDim.x)
-                st_dev(&val[n_leaves + j], ld_dev(&val[node_l[j]]) + ld_dev(&val[node_r[j]]));
+            for (int j = pl.level_off[lv] + threadIdx.x; j < pl.level_off[lv + 1]; j += blockDim.x)
+                st_dev(&val[n_leaves + j], ld_dev(&val[pl.node_l[j]]) + ld_dev(&val[pl.node_r[j]]));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
         }
         if (threadIdx.x == 0)
-            for (int c = 0; c < n_chunks; ++c) total += ld_dev(&val[chunk_root[c]]);
+            for (int c = 0; c < n_chunks; ++c) total += ld_dev(&val[pl.chunk_root[c]]);
     }
+    *total_out = total;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__restrict__ dmin,
+                                                     int32_t *__restrict__ argmin, double *__restrict__ d,
+                                                     int fuse_finish, int last_next, int32_t pos,
+                                                     const uint8_t *__restrict__ is_center,
+                                                     const float *__restrict__ part_max,
+                                                     const int32_t *__restrict__ part_inf, int n_part, int exact_max,
+                                                     float *__restrict__ probs, SumPlan pl) {
+    if (ctl->abort_iter >= 0) return;
+    if (fuse_finish && ctl->fcount[last_next] != 0) {          // the solve did not converge: apply nothing
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
+        return;
+    }
+    float total = 0.0f;
+    if (!kpp_sum_body(ctl, dmin, argmin, d, fuse_finish, pos, is_center, part_max, part_inf, n_part, exact_max, probs,
+                      pl, blockIdx.x, gridDim.x, &total))
+        return;
     if (threadIdx.x == 0) {
         ctl->total = total;
         ctl->ticket[0] = 0;
@@ -336,21 +363,17 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
 }
 
 // The draw.  Every block: tile-local inclusive fp64 scan of p = float64(probs / total) and the tile total.
-// Last block: exclusive tile offsets (sequential order), idx = searchsorted(cdf / cdf[-1], u, side='right') with
-// a safety margin around u -- first the tile whose first value is the last one <= u, then the position inside
-// it -- and the commit: accept or decline the pick; on success also open the next solve.
-__global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const float *__restrict__ probs, int32_t n,
-                                                         double *cdf, double *tile_sum, int n_tiles, double u,
-                                                         double tol, int32_t *centers, uint8_t *is_center,
-                                                         int32_t next_pos, int32_t iter, int begin_next, double *d,
-                                                         int32_t *front0) {
-    if (ctl->abort_iter >= 0) return;
+// Last block: exclusive tile offsets, idx = searchsorted(cdf / cdf[-1], u, side='right') with a safety margin
+// around u -- first the tile whose first value is the last one <= u, then the position inside it.  Returns true in
+// that block, with the pick in pick[0..2] = {found, index, margin ok} (shared memory).
+__device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const float *__restrict__ probs, int32_t n,
+                                              double *cdf, double *tile_sum, int n_tiles, double u, double tol,
+                                              int bid, int nblocks, int32_t *pick) {
     extern __shared__ __attribute__((aligned(16))) double toff[];          // [n_tiles + 1]
     __shared__ double wtot[SCAN_T / 64];
-    __shared__ int32_t s_tile, s_found, s_idx, s_ok;
+    __shared__ int32_t s_tile;
     {
-        const float total = ctl->total;
-        const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+        const int64_t base = (int64_t)bid * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
         double v[SCAN_I];
         double run = 0.0;
 #pragma unroll
@@ -378,9 +401,9 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
 #pragma unroll
         for (int i = 0; i < SCAN_I; ++i)
             if (base + i < n) st_dev(&cdf[base + i], excl + v[i]);
-        if (threadIdx.x == 0) st_dev(&tile_sum[blockIdx.x], tot);
+        if (threadIdx.x == 0) st_dev(&tile_sum[bid], tot);
     }
-    if (!last_block_done(&ctl->ticket[1])) return;
+    if (!last_block_done(&ctl->ticket[1], nblocks)) return false;
     if (threadIdx.x < 64) {                               // exclusive tile offsets: wave scan, 64 tiles a pass
         const int lane = threadIdx.x;
         double carry = 0.0;
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
             if (t < n_tiles) toff[t] = carry + (inc - x);
             carry += __shfl(inc, 63, 64);
         }
-        if (lane == 0) { toff[n_tiles] = carry; s_tile = -1; s_found = 0; s_idx = -1; s_ok = 0; }
+        if (lane == 0) { toff[n_tiles] = carry; s_tile = -1; pick[0] = 0; pick[1] = -1; pick[2] = 0; }
     }
     __syncthreads();
     const double s_last = toff[n_tiles];
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
     __syncthreads();
     const int tile = s_tile;
     if (tile < 0) {                                       // nothing <= u: index 0
-        if (threadIdx.x == 0) { s_found = 1; s_idx = 0; s_ok = (c_at(0) - u > tol) ? 1 : 0; }
+        if (threadIdx.x == 0) { pick[0] = 1; pick[1] = 0; pick[2] = (c_at(0) - u > tol) ? 1 : 0; }
     } else {
 #pragma unroll
         for (int k = 0; k < SCAN_I; ++k) {
@@ -415,18 +438,129 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
             const double cj = in ? c_at(j) : inf64();
             const double cn = last ? inf64() : c_at(j + 1);
             if (in && cj <= u && cn > u) {
-                s_found = 1; s_idx = j + 1;
-                s_ok = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
+                pick[0] = 1; pick[1] = j + 1;
+                pick[2] = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
             }
         }
     }
     __syncthreads();
+    return true;
+}
+
+// scan + pick + commit: accept or decline the pick; on success also open the next solve
+__global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const float *__restrict__ probs, int32_t n,
+                                                         double *cdf, double *tile_sum, int n_tiles, double u,
+                                                         double tol, int32_t *centers, uint8_t *is_center,
+                                                         int32_t next_pos, int32_t iter, int begin_next, double *d,
+                                                         int32_t *front0) {
+    if (ctl->abort_iter >= 0) return;
+    __shared__ int32_t pick[3];
+    if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u, tol, blockIdx.x, gridDim.x, pick)) return;
     if (threadIdx.x == 0) {
         ctl->ticket[1] = 0;
-        if (!s_found || !s_ok) { ctl->abort_iter = iter; ctl->abort_reason = 2; return; }
-        centers[next_pos] = s_idx;
-        is_center[s_idx] = 1;
+        if (!pick[0] || !pick[2]) { ctl->abort_iter = iter; ctl->abort_reason = 2; return; }
+        centers[next_pos] = pick[1];
+        is_center[pick[1]] = 1;
         if (begin_next) kpp_begin(ctl, centers, next_pos, d, front0);
+    }
+}
+
+// ---- the whole chain as ONE kernel launched over and over -------------------------------------------------------
+// A solve's launches cannot be counted in advance (its sweeps end when the frontier is empty), and the host must
+// not wait for every centre.  So every launch runs "the next step": it reads the state the previous launch left
+// (double buffered by launch parity: all blocks read S[parity], one thread writes S[parity ^ 1]) and either
+//   SOLVE: relaxes the current frontier -- or, when that is empty, the solve has converged and the SAME launch
+//          applies it and sums the draw weights (kpp_sum_body); the last centre is only applied;
+//   DRAW:  scans, picks and commits the next centre and opens its solve (kpp_draw_body);
+//   DONE:  nothing (launches enqueued beyond the end of the chain).
+// Used once d_min is finite everywhere (no maximum pass needed); no launch is spent on an empty frontier.
+struct KppState {
+    int32_t mode, t, sw, stamp;        // mode 0 SOLVE, 1 DRAW, 2 DONE; centre index; sweep of its solve; solve counter
+    int32_t launches, pad;
+};
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *state, int parity,
+                                                      const int32_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const float *__restrict__ weights, int32_t n, double *d,
+                                                      float *dmin, int32_t *argmin, int32_t *mark, int32_t *front_a,
+                                                      int32_t *front_b, int32_t *centers, uint8_t *is_center,
+                                                      float *probs, double *cdf, double *tile_sum, int n_tiles,
+                                                      const double *__restrict__ u_dev, double tol, SumPlan pl,
+                                                      int32_t it1, int32_t n_centers_total) {
+    const KppState S = state[parity];
+    KppState *out = &state[parity ^ 1];
+    if (S.mode == 2 || ctl->abort_iter >= 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { KppState x = S; x.mode = 2; *out = x; }
+        return;
+    }
+    if (S.mode == 0) {
+        const int cur = S.sw % 3, next = (S.sw + 1) % 3, clear = (S.sw + 2) % 3;
+        const int32_t cnt = ctl->fcount[cur];
+        if (cnt > 0) {                                                    // one more sweep of this solve
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->fcount[clear] = 0;
+                KppState x = S;
+                x.sw = S.sw + 1; x.launches = S.launches + 1;
+                if (x.sw >= 4094) { ctl->abort_iter = S.t; ctl->abort_reason = 1; x.mode = 2; }   // stamp range
+                *out = x;
+            }
+            kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, (S.sw & 1) ? front_b : front_a,
+                                    (S.sw & 1) ? front_a : front_b, cnt, next, S.stamp * 4096 + S.sw + 1);
+            return;
+        }
+        // converged
+        if (S.t + 1 >= n_centers_total) {                                 // last centre: apply, no draw
+            for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+                const double dd = d[i];
+                if (dd < inf64()) {
+                    const float x = (float)dd;
+                    if (x < dmin[i]) { dmin[i] = x; argmin[i] = S.t; }
+                    d[i] = inf64();
+                }
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) { KppState x = S; x.mode = 2; x.launches = S.launches + 1; *out = x; }
+            return;
+        }
+        const int nsum = (pl.n_leaves + SUM_LEAVES - 1) / SUM_LEAVES;
+        if ((int)blockIdx.x >= nsum) return;
+        float total = 0.0f;
+        if (!kpp_sum_body(ctl, dmin, argmin, d, 1, S.t, is_center, nullptr, nullptr, 0, 0, probs, pl, blockIdx.x, nsum,
+                          &total))
+            return;
+        if (threadIdx.x == 0) {
+            ctl->total = total;
+            ctl->ticket[0] = 0;
+            KppState x = S;
+            x.mode = 1; x.launches = S.launches + 1;
+            if (!(total > 0.0f)) { ctl->abort_iter = S.t; ctl->abort_reason = 3; x.mode = 2; }
+            *out = x;
+        }
+        return;
+    }
+    // DRAW
+    if ((int)blockIdx.x >= n_tiles) return;
+    __shared__ int32_t pick[3];
+    if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u_dev[S.t], tol, blockIdx.x, n_tiles, pick))
+        return;
+    if (threadIdx.x == 0) {
+        ctl->ticket[1] = 0;
+        KppState x = S;
+        x.launches = S.launches + 1;
+        if (!pick[0] || !pick[2]) {
+            ctl->abort_iter = S.t; ctl->abort_reason = 2; x.mode = 2;
+        } else {
+            centers[S.t + 1] = pick[1];
+            is_center[pick[1]] = 1;
+            if (S.t + 1 < it1) {
+                kpp_begin(ctl, centers, S.t + 1, d, front_a);
+                x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
+            } else {
+                x.mode = 2; x.t = S.t + 1;
+            }
+        }
+        *out = x;
     }
 }
 
@@ -462,7 +596,8 @@ struct DevPlan {
 
 struct KppWs {
     KppCtl *ctl;
-    double *d, *cdf, *tile_sum, *tile_off;
+    double *d, *cdf, *tile_sum, *tile_off, *u_dev;
+    KppState *state;
     int32_t *mark, *front[2], *part_inf;
     float *probs, *part_max;
     DevPlan plan;
@@ -478,6 +613,8 @@ size_t plan_ints_bound(int32_t n) {
 bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
     geo::Arena ar(ws, ws_bytes);
     o->ctl = ar.take<KppCtl>(4);
+    o->state = ar.take<KppState>(4);
+    o->u_dev = ar.take<double>((size_t)n);
     o->d = ar.take<double>((size_t)n);
     o->cdf = ar.take<double>((size_t)n);
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
@@ -500,7 +637,7 @@ bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
 extern "C" size_t geo_kpp_workspace_bytes(int32_t n) {
     if (n <= 0) return 4096;
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
-    return geo::align_up(4 * sizeof(KppCtl)) + 2 * geo::align_up((size_t)n * 8) + 2 * geo::align_up((tiles + 1) * 8) +
+    return geo::align_up(4 * sizeof(KppCtl)) + geo::align_up(4 * sizeof(KppState)) + 3 * geo::align_up((size_t)n * 8) + 2 * geo::align_up((tiles + 1) * 8) +
            5 * geo::align_up((size_t)n * 4) + 2 * geo::align_up(FINISH_GRID * 4) +
            2 * geo::align_up(plan_ints_bound(n) * 4) + 4096;
 }
@@ -515,7 +652,9 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
                 "geo_kpp_chain: null pointer");
     GEO_REQUIRE((size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8 <= 64 * 1024, "geo_kpp_chain: n too large for the pick kernel");
     GEO_REQUIRE(n > 0 && 0 <= it0 && it0 <= it1 && it1 <= n_centers_total, "geo_kpp_chain: bad iteration range");
-    GEO_REQUIRE(sweeps_per_solve >= 2 && sweeps_per_solve < 4096 && it1 - it0 < 250000, "geo_kpp_chain: sweeps_per_solve out of range");
+    GEO_REQUIRE(((sweeps_per_solve >= 2 && sweeps_per_solve < 4096) ||
+                 (sweeps_per_solve == 0 && assume_finite && n_centers_total <= n)) && it1 - it0 < 250000,
+                "geo_kpp_chain: sweeps_per_solve out of range (0 = step kernel: needs assume_finite and K <= n)");
     GEO_REQUIRE(it1 - it0 <= 1 || u_host, "geo_kpp_chain: uniform deviates missing");
     KppWs w;
     if (!carve(ws, ws_bytes, n, &w)) {
@@ -581,6 +720,60 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     kpp_maxfin_kernel<<<1, 64, 0, s>>>(w.ctl, w.part_max, w.part_inf, FINISH_GRID);
     if (it0 < it1) kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, it0, w.d, w.front[0]);
     GEO_LAUNCH_CHECK();
+    SumPlan spl;
+    spl.leaf_start = dp.leaf_start; spl.leaf_len = dp.leaf_len; spl.node_l = dp.node_l; spl.node_r = dp.node_r;
+    spl.level_off = dp.level_off; spl.chunk_root = dp.chunk_root;
+    spl.n_leaves = dp.n_leaves; spl.n_levels = dp.n_levels; spl.n_chunks = dp.n_chunks; spl.val = dp.val;
+    if (sweeps_per_solve == 0 && it0 < it1) {
+        // ---- step-kernel mode: one kernel, launched until the chain reports DONE ----
+        if (n_centers_total > 1)
+            GEO_HIP_CHECK(hipMemcpyAsync(w.u_dev, u_host, (size_t)(n_centers_total - 1) * sizeof(double), hipMemcpyHostToDevice, s));
+        KppState st0;
+        st0.mode = 0; st0.t = it0; st0.sw = 0; st0.stamp = 1; st0.launches = 0; st0.pad = 0;
+        GEO_HIP_CHECK(hipMemcpyAsync(w.state, &st0, sizeof(KppState), hipMemcpyHostToDevice, s));
+        const int nsum = (dp.n_leaves + SUM_LEAVES - 1) / SUM_LEAVES;
+        int g_small = 256;
+        if (nsum > g_small) g_small = nsum;
+        if (n_tiles > g_small) g_small = n_tiles;
+        const size_t smem = (size_t)(n_tiles + 1) * sizeof(double);
+        int64_t launched = 0;
+        int32_t batch = 64, t_now = it0;
+        KppState hs = st0;
+        KppCtl hc;
+        for (;;) {
+            const int grid = t_now < 16 && g_push_big > g_small ? g_push_big : g_small;
+            for (int32_t i = 0; i < batch; ++i, ++launched) {
+                const int parity = (int)(launched & 1);
+                if (weights)
+                    kpp_step_kernel<true><<<grid, 256, smem, s>>>(w.ctl, w.state, parity, indptr, indices, weights, n, w.d, dmin,
+                                                                  argmin, w.mark, w.front[0], w.front[1], centers, is_center,
+                                                                  w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, it1,
+                                                                  n_centers_total);
+                else
+                    kpp_step_kernel<false><<<grid, 256, smem, s>>>(w.ctl, w.state, parity, indptr, indices, weights, n, w.d, dmin,
+                                                                   argmin, w.mark, w.front[0], w.front[1], centers, is_center,
+                                                                   w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, it1,
+                                                                   n_centers_total);
+            }
+            GEO_LAUNCH_CHECK();
+            GEO_HIP_CHECK(hipMemcpyAsync(&hs, w.state + (launched & 1), sizeof(KppState), hipMemcpyDeviceToHost, s));
+            GEO_HIP_CHECK(hipMemcpyAsync(&hc, w.ctl, sizeof(KppCtl), hipMemcpyDeviceToHost, s));
+            GEO_HIP_CHECK(hipStreamSynchronize(s));
+            if (hs.mode == 2 || hc.abort_iter >= 0) break;
+            // launches still needed ~ centres left x launches per centre so far (+10 %), at most 1024 per round trip
+            const int32_t done_centres = hs.t - it0 > 0 ? hs.t - it0 : 1;
+            const double per_centre = (double)hs.launches / done_centres;
+            const double est = (double)(it1 - hs.t) * per_centre * 1.1 + 8.0;
+            batch = est > 1024.0 ? 1024 : (int32_t)est;
+            t_now = hs.t;
+            GEO_REQUIRE(launched < ((int64_t)1 << 31), "geo_kpp_chain: step kernel did not finish");
+        }
+        status_out[0] = hc.abort_iter;
+        status_out[1] = hc.abort_reason;
+        status_out[2] = hc.n_inf;
+        status_out[3] = (int32_t)(hs.launches);
+        return GEO_OK;
+    }
     for (int32_t t = it0; t < it1; ++t) {
         const int32_t stamp_solve = (t - it0) + 1;
         int last_next = 0;
@@ -605,8 +798,7 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
             if (exact_max) kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max, w.part_inf);
             kpp_sum_kernel<<<(dp.n_leaves + SUM_LEAVES - 1) / SUM_LEAVES, 256, 0, s>>>(
                 w.ctl, dmin, argmin, w.d, fuse, last_next, t, is_center, w.part_max, w.part_inf, FINISH_GRID, exact_max,
-                w.probs, dp.leaf_start, dp.leaf_len, dp.n_leaves, dp.node_l, dp.node_r, dp.level_off, dp.n_levels,
-                dp.chunk_root, dp.n_chunks, dp.val);
+                w.probs, spl);
             kpp_draw_kernel<<<n_tiles, SCAN_T, (size_t)(n_tiles + 1) * sizeof(double), s>>>(
                 w.ctl, w.probs, n, w.cdf, w.tile_sum, n_tiles, u_host[t], tol, centers, is_center, t + 1, t,
                 t + 1 < it1 ? 1 : 0, w.d, w.front[0]);

@@ -133,21 +133,25 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     ws = workspace(lib.geo_kpp_workspace_bytes(N), dev)
     it, it1 = 0, (K if absorb_last else K - 1)
     n_valid = K
-    # Sweeps enqueued per solve: a solve exits early once converged, but every enqueued launch costs ~2 us, and a
-    # solve that needs more than were enqueued aborts and is redone.  The need is the hop radius of the new
-    # centre's (pruned) cell: the whole graph for the first centre, then shrinking.  So the chain runs in
-    # segments of doubling length; each takes its budget from what the previous one needed.
+    # While d_min still has unreachable (inf) entries the chain runs as separate kernels per phase with a sweep
+    # budget per solve: a solve exits early once converged, but every enqueued launch costs ~2 us, and a solve that
+    # needs more than were enqueued aborts and is redone.  The need is the hop radius of the new centre's (pruned)
+    # cell: the whole graph for the first centre, then shrinking -- segments of doubling length, each taking its
+    # budget from what the previous one needed.  Once d_min is finite everywhere (after the first centre on a
+    # connected graph) the rest of the chain is ONE kernel launched over and over that always does "the next
+    # step" (csrc/kpp.hip, kpp_step_kernel): no budget, no launch spent on an empty frontier.
     fixed = os.environ.get("GEO_KPP_SWEEPS")
     budget, seg, cap = (int(fixed) if fixed else 16), 1, 4094
     finite = False
     status = np.zeros(4, dtype=np.int32)
     while it < it1:
-        seg_end = min(it1, it + seg)
+        step_mode = finite and not fixed and K <= N
+        seg_end = it1 if step_mode else min(it1, it + seg)
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
                                          ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
-                                         K, budget, 1 if finite else 0, ptr(ws), ws.numel(), status.ctypes.data,
-                                         stream_ptr()),
+                                         K, 0 if step_mode else budget, 1 if finite else 0, ptr(ws), ws.numel(),
+                                         status.ctypes.data, stream_ptr()),
                        "geo_kpp_chain")
         t, reason, used = int(status[0]), int(status[1]), int(status[3])
         finite = finite or int(status[2]) == 0          # inf entries only ever disappear from d_min
@@ -155,10 +159,10 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
             chain.solves += seg_end - it
             it = seg_end
             seg = min(2 * seg, 256)
-            if not fixed:
+            if not fixed and not step_mode:
                 budget = min(cap, max(4, used + used // 8 + 1))     # cells shrink: the next segment needs no more
             continue
-        if reason == 1 and budget < cap:                 # nothing of solve t was applied: redo it with more sweeps
+        if reason == 1 and not step_mode and budget < cap:   # nothing of solve t was applied: redo it with more sweeps
             chain.solves += t - it
             budget, seg, it = min(cap, 4 * budget), 1, t
             continue
