@@ -78,7 +78,7 @@ __device__ __forceinline__ void kpp_push_body(KppCtl *ctl, const int32_t *__rest
                                               const int32_t *__restrict__ indices, const float *__restrict__ weights,
                                               double *d, const float *__restrict__ dmin, int32_t *mark,
                                               const int32_t *__restrict__ fin, int32_t *__restrict__ fout, int32_t cnt,
-                                              int next, int32_t stamp) {
+                                              int next, int32_t stamp, bool pretest) {
     const double tau = ctl->maxf > 0.f ? 1e-6 * (double)ctl->maxf : 0.0;
     const int sub = threadIdx.x & 31, lane = threadIdx.x & 63;       // 32 lanes per frontier node (mean degree ~31)
     const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -94,7 +94,11 @@ __device__ __forceinline__ void kpp_push_body(KppCtl *ctl, const int32_t *__rest
             const double cand = du + (WEIGHTED ? (double)weights[e] : 1.0);
             const unsigned long long cb = (unsigned long long)__double_as_longlong(cand);
             bool queue = false;
-            if (cb < dbits[v]) {                            // cheap pre-test (monotone: values only decrease)
+            // large frontiers: a plain read first (monotone: values only decrease) spares most atomics;
+            // small ones: the atomic straight away spares a dependent round trip
+            bool go = true;
+            if (pretest) go = cb < dbits[v];
+            if (go) {
                 const unsigned long long old = atomicMin(&dbits[v], cb);
                 if (cb < old && cand <= (double)dmin[v] + tau) queue = atomicMax(&mark[v], stamp) < stamp;
             }
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_
     if (cnt == 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0 && sw + 1 > ctl->max_sw) ctl->max_sw = sw + 1;   // launches are serial
     kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, fin, fout, cnt, next,
-                            stamp_solve * 4096 + sw + 1);
+                            stamp_solve * 4096 + sw + 1, true);
 }
 
 // d_min / argmin update (kmeans_optimized.py:44 + the single-pass assignment) outside the fused path below;
@@ -480,7 +484,7 @@ struct KppState {
 };
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *state, int parity,
+__global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *state, int lidx,
                                                       const int32_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices,
                                                       const float *__restrict__ weights, int32_t n, double *d,
@@ -489,6 +493,12 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
                                                       float *probs, double *cdf, double *tile_sum, int n_tiles,
                                                       const double *__restrict__ u_dev, double tol, SumPlan pl,
                                                       int32_t it1, int32_t n_centers_total) {
+    // lidx = launch index mod 6: state parity, frontier-count ring slot and queue buffer all follow the launch
+    // index, so their addresses are known before the state arrives (one dependent round trip less per launch)
+    const int parity = lidx & 1;
+    const int cur = lidx % 3, next = (lidx + 1) % 3, clear = (lidx + 2) % 3;
+    int32_t *fin = parity ? front_b : front_a, *fout = parity ? front_a : front_b;
+    const int32_t cnt = ctl->fcount[cur];
     const KppState S = state[parity];
     KppState *out = &state[parity ^ 1];
     if (S.mode == 2 || ctl->abort_iter >= 0) {
@@ -496,8 +506,6 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         return;
     }
     if (S.mode == 0) {
-        const int cur = S.sw % 3, next = (S.sw + 1) % 3, clear = (S.sw + 2) % 3;
-        const int32_t cnt = ctl->fcount[cur];
         if (cnt > 0) {                                                    // one more sweep of this solve
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 ctl->fcount[clear] = 0;
@@ -506,8 +514,8 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
                 if (x.sw >= 4094) { ctl->abort_iter = S.t; ctl->abort_reason = 1; x.mode = 2; }   // stamp range
                 *out = x;
             }
-            kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, (S.sw & 1) ? front_b : front_a,
-                                    (S.sw & 1) ? front_a : front_b, cnt, next, S.stamp * 4096 + S.sw + 1);
+            kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, fin, fout, cnt, next,
+                                    S.stamp * 4096 + S.sw + 1, cnt >= 2048);
             return;
         }
         // converged
@@ -553,8 +561,12 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         } else {
             centers[S.t + 1] = pick[1];
             is_center[pick[1]] = 1;
-            if (S.t + 1 < it1) {
-                kpp_begin(ctl, centers, S.t + 1, d, front_a);
+            if (S.t + 1 < it1) {                                          // the next launch reads slot `next`, queue `fout`
+                const int32_t src = pick[1];
+                d[src] = 0.0;
+                fout[0] = src;
+                ctl->fcount[next] = 1;
+                ctl->fcount[clear] = 0;
                 x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
             } else {
                 x.mode = 2; x.t = S.t + 1;
@@ -743,7 +755,7 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
         for (;;) {
             const int grid = t_now < 16 && g_push_big > g_small ? g_push_big : g_small;
             for (int32_t i = 0; i < batch; ++i, ++launched) {
-                const int parity = (int)(launched & 1);
+                const int parity = (int)(launched % 6);
                 if (weights)
                     kpp_step_kernel<true><<<grid, 256, smem, s>>>(w.ctl, w.state, parity, indptr, indices, weights, n, w.d, dmin,
                                                                   argmin, w.mark, w.front[0], w.front[1], centers, is_center,
