@@ -53,6 +53,8 @@ size_t geo_sssp_workspace_bytes(int32_t n, int64_t nnz, int32_t n_sources);
  * (column minimum over the S rows of the f32 matrix and the FIRST row index attaining it,
  * = D.argmin(axis=0) of kmeans_optimized.py:100; all-inf column -> 0).  Any output may be NULL.
  * sweeps_out [host, may be NULL] receives the number of relaxation sweeps launched.
+ * Internally the sources may be relaxed in another order than given (batches of neighbouring sources on graphs
+ * with long geodesics); every output is in the caller's order and does not depend on that.
  * Synchronises. */
 int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights,
                    int32_t n, int64_t nnz, const int32_t *sources, int32_t n_sources,
