@@ -112,6 +112,54 @@ def test_ragged_sizes_vs_oracle():
         np.testing.assert_array_equal(W.data, Wo.data)
 
 
+def _oracle_rows(z, n_neighbors, form, r0, r1):
+    import ctypes
+    from oracle import _clib
+    io = np.empty((r1 - r0, n_neighbors), np.int64)
+    do = np.empty((r1 - r0, n_neighbors), np.float64)
+    _clib.lib().oracle_knn(ctypes.c_void_p(z.ctypes.data), z.shape[0], z.shape[1], n_neighbors, form, r0, r1,
+                           ctypes.c_void_p(io.ctypes.data), ctypes.c_void_p(do.ctypes.data))
+    return io, do
+
+
+@pytest.mark.parametrize("d,filt", [(16, "1"), (8, "1"), (24, "1"), (16, "0")])
+def test_large_corpus_filter_path_vs_oracle(d, filt, monkeypatch):
+    """Above 40 000 rows the search runs behind the float32 matrix-core filter (subset thresholds, MFMA scan, exact
+    fp64 refinement of the kept candidates); lists and fp64 keys must equal the oracle's, as without the filter --
+    expansion form (d > 15), direct form (d <= 15) and a padded dimension (24 -> 32)."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    monkeypatch.setenv("GEO_KNN_FILTER", filt)
+    n, kq = 45000, 21
+    z = latents(n, d, 21)
+    idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for r0, r1 in ((0, 48), (22000, 22048), (n - 48, n)):
+        io, do = _oracle_rows(z, kq, 1 if d > 15 else 0, r0, r1)
+        np.testing.assert_array_equal(idx[r0:r1], io)
+        np.testing.assert_array_equal(d2[r0:r1], do)
+    assert (idx[:, 0] == np.arange(n)).all() and (np.diff(d2, axis=1) >= 0).all()
+
+
+def test_large_corpus_with_masses_of_duplicates_falls_back():
+    """3 000 copies of one point overflow the candidate lists of the filter (cap 1024): the search must notice and
+    answer with the exact scan.  Ties among exact duplicates: (distance, index) order."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    n, d, kq = 42000, 16, 21
+    z = latents(n, d, 22)
+    z[5000:8000] = z[5000]
+    idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for r0, r1 in ((0, 32), (5000, 5032), (7968, 8000)):
+        io, do = _oracle_rows(z, kq, 1, r0, r1)
+        np.testing.assert_array_equal(d2[r0:r1], do)
+        np.testing.assert_array_equal(idx[r0:r1], io)
+    assert (d2[5000:8000] == 0).all() and (idx[5000:8000, 0] == 5000).all()     # lowest indices among the copies first
+
+
 def test_lcc_and_connectivity(golden):
     from vqvae_amd.geo.knn_graph_optimized import (analyze_graph_connectivity, build_knn_graph,
                                                    largest_connected_component)

@@ -15,6 +15,8 @@
 // steps (k * ln(N/k) per query), the loop is bound by the fp64 FMA rate.
 #include "geo_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int KNN_WAVES = 4;
@@ -46,9 +48,9 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
 
 template <int DCH, int Q, bool EXPANSION>
 __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32, const double *__restrict__ zq64,
-                                                 const double *__restrict__ nrm, int64_t n, int nch, int kq,
-                                                 int64_t row0, int64_t row1, int32_t *__restrict__ idx_out,
-                                                 double *__restrict__ d2_out) {
+                                                 const double *__restrict__ nrm, const double *__restrict__ nrm_q,
+                                                 int64_t n, int nch, int kq, int64_t row0, int64_t row1,
+                                                 int32_t *__restrict__ idx_out, double *__restrict__ d2_out) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t q0 = row0 + ((int64_t)blockIdx.x * KNN_WAVES + wave) * Q;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
             if (EXPANSION) {
                 int64_t qr = q0 + q;
                 if (qr >= row1) qr = row1 - 1;
-                d2 = (nrm[qr] + (-2.0 * d2)) + nj;
+                d2 = (nrm_q[qr] + (-2.0 * d2)) + nj;
                 if (!(d2 > 0.0)) d2 = 0.0;
             }
             unsigned long long hits = __ballot(valid && d2 < tau[q]);
@@ -130,6 +132,224 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
     }
 }
 
+// ---- exact search behind a float32 matrix-core filter (large corpora) -----------------------------------------------
+// 1. tau[i] = the kq-th smallest exact distance from query i to every FILTER_STRIDE-th corpus row: an upper bound of
+//    the kq-th smallest over the whole corpus (knn_kernel on the subset).
+// 2. knn_scan_kernel: approximate squared distances of ALL pairs on the matrix cores (v_mfma_f32_32x32x2_f32, expansion
+//    form with the fp64 norms); pair (i, j) is kept when  approx <= tau[i] + eps * (|x_i|^2 + |x_j|^2),  eps far above
+//    the rounding of a d-term float32 dot product -- every true neighbour is kept, plus ~FILTER_STRIDE * kq others.
+// 3. knn_refine_kernel: the kept candidates are re-evaluated with the same fp64 fma chains as knn_kernel and ranked
+//    by (distance, index): the result is the one knn_kernel gives.  A query whose list overflows FILTER_CAP (heavily
+//    duplicated points) is reported and the caller falls back to knn_kernel.
+constexpr int FILTER_STRIDE = 16, FILTER_CAP = 1024, SCAN_CT = 128;      // candidates staged per LDS tile
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void knn_subset_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
+                                                        int64_t n, int dp, int stride, int64_t m,
+                                                        float *__restrict__ zs32, double *__restrict__ nrm_s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m * dp; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dp;
+        const int c = (int)(i % dp);
+        zs32[i] = zp32[r * stride * dp + c];
+        if (c == 0) nrm_s[r] = nrm[r * stride];
+    }
+}
+
+// u[i] = tau[i] - |x_i|^2 (1 - eps): the scan keeps (i, j) when  |x_j|^2 (1 - eps) - 2 x_i.x_j <= u[i]
+__global__ __launch_bounds__(256) void knn_tau_kernel(const double *__restrict__ d2_sub, const double *__restrict__ nrm,
+                                                     int64_t row0, int64_t rows, int kq, double eps,
+                                                     double *__restrict__ u, int32_t *__restrict__ cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        const double nq = nrm[row0 + i];
+        u[i] = d2_sub[i * kq + (kq - 1)] + eps * nq - nq;
+        cnt[i] = 0;
+    }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
+                                                      const double *__restrict__ u, int64_t n, int64_t row0, int64_t rows,
+                                                      double eps, int splits, int32_t *__restrict__ cnt,
+                                                      int32_t *__restrict__ list) {
+    // The whole test runs on the matrix cores: with A = [-2 x_i, 1, -u_i] and B = [x_j, |x_j|^2 (1 - eps), 1] the
+    // product is  |x_j|^2 (1 - eps) - 2 x_i.x_j - u_i,  negative exactly for the pairs to keep (u rounded up, the norm
+    // rounded down to float32; eps covers the float32 roundings of the accumulation).
+    constexpr int KI = DP / 2 + 1;                             // MFMA steps (2-deep each), the last one carries the test
+    __shared__ float Bs[2][SCAN_CT / 32][KI][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t qbase = (int64_t)(blockIdx.x / splits) * 128 + wave * 32;   // this wave's 32 queries (local row numbers)
+    const int split = blockIdx.x % splits;                                  // ... against one slice of the corpus
+    // A operand: lane holds A[m = r][k = 2i + h]
+    float a[KI];
+    {
+        const bool live = qbase + r < rows;
+        const int64_t q = live ? qbase + r : rows - 1;
+#pragma unroll
+        for (int i = 0; i < KI - 1; ++i) a[i] = -2.0f * zp32[(row0 + q) * DP + 2 * i + h];
+        float ur = -3.0e38f;                                   // padded queries keep nothing
+        if (live) {
+            const double ud = u[q];
+            ur = (float)ud;
+            if ((double)ur < ud) ur = nextafterf(ur, 3.4e38f);
+        }
+        a[KI - 1] = h == 0 ? 1.0f : -ur;
+    }
+    const int64_t all_tiles = (n + SCAN_CT - 1) / SCAN_CT, per_split = (all_tiles + splits - 1) / splits;
+    const int64_t tile_lo = per_split * split;
+    const int64_t n_tiles = tile_lo + per_split < all_tiles ? tile_lo + per_split : all_tiles;
+    if (tile_lo >= n_tiles) return;
+    // staging in two halves: the global loads of the next tile are issued before the MFMAs of the current one and
+    // written to the other LDS buffer after them
+    constexpr int PER = SCAN_CT * DP / 256;                    // floats per thread: (candidate, slice of its row)
+    const int sc = (threadIdx.x * PER) / DP, sk0 = (threadIdx.x * PER) % DP;
+    float vals[PER];
+    float nval = 3.0e38f;
+    auto fetch = [&](int64_t tile) {
+        const int64_t c0 = tile * SCAN_CT;
+        const int64_t j = c0 + sc < n ? c0 + sc : n - 1;
+#pragma unroll
+        for (int k = 0; k < PER; k += 4) {
+            const float4 f = *reinterpret_cast<const float4 *>(zp32 + j * DP + sk0 + k);
+            vals[k] = f.x; vals[k + 1] = f.y; vals[k + 2] = f.z; vals[k + 3] = f.w;
+        }
+        if (threadIdx.x < SCAN_CT) {
+            const int64_t jj = c0 + threadIdx.x;
+            nval = 3.0e38f;                                    // beyond the corpus: never kept
+            if (jj < n) {
+                const double nd = nrm[jj] * (1.0 - eps);
+                nval = (float)nd;
+                if ((double)nval > nd) nval = nextafterf(nval, -3.4e38f);
+            }
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int kk = sk0 + k;
+            Bs[buf][sc >> 5][kk >> 1][(kk & 1) * 32 + (sc & 31)] = vals[k];
+        }
+        if (threadIdx.x < SCAN_CT) {
+            Bs[buf][threadIdx.x >> 5][KI - 1][threadIdx.x & 31] = nval;
+            Bs[buf][threadIdx.x >> 5][KI - 1][32 + (threadIdx.x & 31)] = 1.0f;
+        }
+    };
+    fetch(tile_lo);
+    put((int)(tile_lo & 1));
+    __syncthreads();
+    for (int64_t tile = tile_lo; tile < n_tiles; ++tile) {
+        const int buf = (int)(tile & 1);
+        if (tile + 1 < n_tiles) fetch(tile + 1);
+#pragma unroll
+        for (int t = 0; t < SCAN_CT / 32; t += 2) {           // two column tiles in flight: independent accumulators
+            f32x16v acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bs[buf][t][i][lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bs[buf][t + 1][i][lane], acc1, 0, 0, 0);
+            }
+            unsigned any0 = 0, any1 = 0;                       // sign bits: a negative entry = a pair to keep
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { any0 |= __float_as_uint(acc0[q]); any1 |= __float_as_uint(acc1[q]); }
+            if ((any0 | any1) & 0x80000000u) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int32_t cand = (int32_t)(tile * SCAN_CT + (t + tt) * 32 + r);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if ((tt ? acc1[q] : acc0[q]) < 0.0f) {
+                            const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            const int32_t slot = atomicAdd(&cnt[row], 1);
+                            if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                        }
+                    }
+                }
+            }
+        }
+        if (tile + 1 < n_tiles) put(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// one wave per query: exact fp64 distances of its kept candidates (same fma chains as knn_kernel) into LDS, then the
+// kq smallest in (distance, index) order -- the lists are a few hundred entries, unordered
+template <int DCH, bool EXPANSION>
+__global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict__ zp32, const double *__restrict__ zq64,
+                                                        const double *__restrict__ nrm, int nch, int kq, int64_t row0,
+                                                        int64_t rows, const int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ list, int32_t *__restrict__ idx_out,
+                                                        double *__restrict__ d2_out, int32_t *__restrict__ overflow) {
+    __shared__ double sv[KNN_WAVES][FILTER_CAP];
+    __shared__ int32_t si[KNN_WAVES][FILTER_CAP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * KNN_WAVES + wave;
+    if (row >= rows) return;
+    const int dp = nch * DCH;
+    const int32_t m_all = cnt[row];
+    if (m_all > FILTER_CAP) { if (lane == 0) atomicAdd(overflow, 1); return; }
+    const int64_t qr = row0 + row;
+    for (int32_t c0 = 0; c0 < m_all; c0 += 64) {
+        const bool valid = c0 + lane < m_all;
+        const int32_t j = valid ? list[row * FILTER_CAP + c0 + lane] : 0;
+        double acc = 0.0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const float4 *src = reinterpret_cast<const float4 *>(zp32 + (int64_t)j * dp + ch * DCH);
+            const double *__restrict__ qv = zq64 + qr * dp + ch * DCH;     // wave-uniform address
+#pragma unroll
+            for (int v = 0; v < DCH / 4; ++v) {
+                const float4 f = src[v];
+                const double c4[4] = {(double)f.x, (double)f.y, (double)f.z, (double)f.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (EXPANSION) {
+                        acc = fma(qv[4 * v + k], c4[k], acc);
+                    } else {
+                        const double t = qv[4 * v + k] - c4[k];
+                        acc = fma(t, t, acc);
+                    }
+                }
+            }
+        }
+        double d2 = acc;
+        if (EXPANSION) {
+            d2 = (nrm[qr] + (-2.0 * d2)) + nrm[j];
+            if (!(d2 > 0.0)) d2 = 0.0;
+        }
+        if (valid) { sv[wave][c0 + lane] = d2; si[wave][c0 + lane] = j; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's own LDS writes, read back below
+    __builtin_amdgcn_wave_barrier();
+    // kq rounds of "extract the minimum in (distance, index) order": every lane scans its own strided entries,
+    // a butterfly finds the wave's minimum, its owner retires it
+    for (int round = 0; round < kq; ++round) {
+        double bv = inf64();
+        int32_t bi = 0x7fffffff, bpos = -1;
+        for (int32_t e = lane; e < m_all; e += 64) {
+            const double v = sv[wave][e];
+            const int32_t id = si[wave][e];
+            if (v < bv || (v == bv && id < bi)) { bv = v; bi = id; bpos = e; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int32_t oi = __shfl_xor(bi, off, 64);
+            const int32_t op = __shfl_xor(bpos, off, 64);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
+        }
+        if (bpos < 0) break;                                   // fewer candidates than kq (cannot happen: subset >= kq rows)
+        if (lane == (bpos & 63)) sv[wave][bpos] = inf64();     // retired (real distances are finite)
+        if (lane == 0) {
+            idx_out[row * kq + round] = bi;
+            d2_out[row * kq + round] = bv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct KnnPlan { int dch, nch, dp; };
 
 KnnPlan plan_for(int d) {
@@ -142,17 +362,26 @@ KnnPlan plan_for(int d) {
 }
 
 template <int DCH, int Q>
-int launch_knn(bool expansion, const float *zp32, const double *zq64, const double *nrm, int64_t n, int nch, int kq,
-               int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out, hipStream_t s) {
+int launch_knn(bool expansion, const float *zp32, const double *zq64, const double *nrm, const double *nrm_q, int64_t n,
+               int nch, int kq, int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out, hipStream_t s) {
     const int64_t rows = row1 - row0;
     const int64_t waves = (rows + Q - 1) / Q;
     const unsigned grid = (unsigned)((waves + KNN_WAVES - 1) / KNN_WAVES);
     if (expansion)
-        knn_kernel<DCH, Q, true><<<grid, 256, 0, s>>>(zp32, zq64, nrm, n, nch, kq, row0, row1, idx_out, d2_out);
+        knn_kernel<DCH, Q, true><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
     else
-        knn_kernel<DCH, Q, false><<<grid, 256, 0, s>>>(zp32, zq64, nrm, n, nch, kq, row0, row1, idx_out, d2_out);
+        knn_kernel<DCH, Q, false><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
     GEO_LAUNCH_CHECK();
     return GEO_OK;
+}
+
+
+
+bool filter_applies(int64_t n, int dp) {
+    if (const char *e = getenv("GEO_KNN_FILTER")) {
+        if (atoi(e) == 0) return false;
+    }
+    return n >= 40000 && (dp == 8 || dp == 16 || dp == 32);
 }
 
 }  // namespace
@@ -160,8 +389,14 @@ int launch_knn(bool expansion, const float *zp32, const double *zq64, const doub
 extern "C" size_t geo_knn_workspace_bytes(int64_t n, int32_t d) {
     if (n <= 0 || d <= 0) return 1024;
     const KnnPlan p = plan_for(d);
-    return geo::align_up((size_t)n * p.dp * sizeof(float)) + geo::align_up((size_t)n * p.dp * sizeof(double)) +
-           geo::align_up((size_t)n * sizeof(double)) + 1024;
+    size_t b = geo::align_up((size_t)n * p.dp * sizeof(float)) + geo::align_up((size_t)n * p.dp * sizeof(double)) +
+               geo::align_up((size_t)n * sizeof(double)) + 1024;
+    if (filter_applies(n, p.dp)) {
+        const size_t m = ((size_t)n + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        b += geo::align_up(m * p.dp * sizeof(float)) + geo::align_up(m * sizeof(double)) + geo::align_up((size_t)n * 8) +
+             geo::align_up((size_t)n * 4) + geo::align_up((size_t)n * FILTER_CAP * 4) + 256;
+    }
+    return b;
 }
 
 extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neighbors, int32_t form, int64_t row0,
@@ -187,16 +422,63 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
     knn_prep_kernel<<<geo::grid_for(n, 256, 4096), 256, 0, stream>>>(z, n, d, p.dp, zp32, zq64, nrm);
     GEO_LAUNCH_CHECK();
     const bool ex = form != 0;
-    const bool small = (row1 - row0) < 16384;     // fewer queries per wave keeps the chip busy on small inputs
+    const int64_t rows = row1 - row0;
+    if (filter_applies(n, p.dp) && (n + FILTER_STRIDE - 1) / FILTER_STRIDE >= n_neighbors) {
+        const int64_t m = (n + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        float *zs32 = ar.take<float>((size_t)m * p.dp);
+        double *nrm_s = ar.take<double>((size_t)m);
+        double *u = ar.take<double>((size_t)n);
+        int32_t *cnt = ar.take<int32_t>((size_t)n);
+        int32_t *list = ar.take<int32_t>((size_t)n * FILTER_CAP);
+        int32_t *overflow = ar.take<int32_t>(16);
+        if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow) {
+            geo::set_error("geo_knn_topk: workspace %zu too small", ws_bytes);
+            return GEO_E_WORKSPACE;
+        }
+        // a d-term float32 dot product errs by < (d + 2) 2^-24 |x||y|, |x||y| <= (|x|^2 + |y|^2) / 2, and the float32
+        // test adds a few more roundings of the same size: 16x margin
+        const double eps = 16.0 * (p.dp + 2) * 5.9604644775390625e-08;
+        GEO_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, stream));
+        knn_subset_kernel<<<geo::grid_for(m * p.dp, 256, 4096), 256, 0, stream>>>(zp32, nrm, n, p.dp, FILTER_STRIDE, m, zs32, nrm_s);
+        GEO_LAUNCH_CHECK();
+        int rc;
+        if (p.dch == 8) rc = launch_knn<8, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        else if (p.dch == 16) rc = launch_knn<16, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        else rc = launch_knn<32, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        if (rc) return rc;
+        knn_tau_kernel<<<geo::grid_for(rows, 256, 4096), 256, 0, stream>>>(d2_out, nrm, row0, rows, n_neighbors, eps, u, cnt);
+        GEO_LAUNCH_CHECK();
+        const int splits = (int)((int64_t)16384 / ((rows + 127) / 128) > 1 ? ((int64_t)16384 / ((rows + 127) / 128) > 64 ? 64 : (int64_t)16384 / ((rows + 127) / 128)) : 1);
+        const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
+        if (p.dp == 8) knn_scan_kernel<8><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else if (p.dp == 16) knn_scan_kernel<16><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else knn_scan_kernel<32><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        GEO_LAUNCH_CHECK();
+        const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
+#define GEO_REFINE(DCHV, EXV) \
+    knn_refine_kernel<DCHV, EXV><<<rgrid, 256, 0, stream>>>(zp32, zq64, nrm, p.nch, n_neighbors, row0, rows, cnt, list, \
+                                                          idx_out, d2_out, overflow)
+        if (p.dch == 8) { if (ex) GEO_REFINE(8, true); else GEO_REFINE(8, false); }
+        else if (p.dch == 16) { if (ex) GEO_REFINE(16, true); else GEO_REFINE(16, false); }
+        else { if (ex) GEO_REFINE(32, true); else GEO_REFINE(32, false); }
+#undef GEO_REFINE
+        GEO_LAUNCH_CHECK();
+        int32_t h_over = 0;
+        GEO_HIP_CHECK(hipMemcpyAsync(&h_over, overflow, 4, hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_over == 0) return GEO_OK;
+        // some query kept more than FILTER_CAP candidates (masses of near-duplicates): exact scan for everything
+    }
+    const bool small = rows < 16384;              // fewer queries per wave keeps the chip busy on small inputs
     int rc;
     if (p.dch == 8)
-        rc = small ? launch_knn<8, 4>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
-                   : launch_knn<8, 16>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        rc = small ? launch_knn<8, 4>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
+                   : launch_knn<8, 16>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
     else if (p.dch == 16)
-        rc = small ? launch_knn<16, 4>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
-                   : launch_knn<16, 16>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        rc = small ? launch_knn<16, 4>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
+                   : launch_knn<16, 16>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
     else
-        rc = small ? launch_knn<32, 4>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
-                   : launch_knn<32, 16>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        rc = small ? launch_knn<32, 4>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)
+                   : launch_knn<32, 16>(ex, zp32, zq64, nrm, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
     return rc;
 }
