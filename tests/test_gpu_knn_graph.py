@@ -142,6 +142,19 @@ def test_large_corpus_filter_path_vs_oracle(d, filt, monkeypatch):
     assert (idx[:, 0] == np.arange(n)).all() and (np.diff(d2, axis=1) >= 0).all()
 
 
+def test_large_corpus_row_ranges_equal_the_full_search():
+    """Query-row shards (the multi-rank layout, parallel.sharded_knn) of a corpus that takes the filter path."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    n, kq = 45000, 21
+    z = torch.from_numpy(latents(n, 16, 23)).to(device())
+    idx, d2 = knn_search_device(z, kq)
+    for r0, r1 in ((0, 11250), (11250, 30001), (30001, n)):
+        i_s, d_s = knn_search_device(z, kq, r0, r1)
+        assert torch.equal(i_s, idx[r0:r1]) and torch.equal(d_s, d2[r0:r1])
+
+
 def test_large_corpus_with_masses_of_duplicates_falls_back():
     """3 000 copies of one point overflow the candidate lists of the filter (cap 1024): the search must notice and
     answer with the exact scan.  Ties among exact duplicates: (distance, index) order."""
