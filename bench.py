@@ -50,6 +50,17 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -142,7 +153,8 @@ def cpu_baseline(res, z, dec, cfg):
     t_solve = (time.perf_counter() - t0) / min(n_src, len(res["medoids"]))
     t_kmed = t_solve * (3 * K - 1)
     total = t_knn + t_jvp + t_kmed
-    return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port",
+    return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "host_logical_cpus": os.cpu_count(),
             "sample": (f"oracle on host: kNN {rows}/{n} query rows x{n / rows:.0f}, JVP {e_s}/{E} edges x{E / e_s:.0f} "
                        f"(torch CPU, {cores} threads), Dijkstra {n_src} sources x{(3 * K - 1) / n_src:.0f} "
                        f"(reference runs 3K-1 = {3 * K - 1} single-thread solves)"),
