@@ -122,7 +122,7 @@ def _oracle_rows(z, n_neighbors, form, r0, r1):
     return io, do
 
 
-@pytest.mark.parametrize("d,filt", [(16, "1"), (8, "1"), (24, "1"), (16, "0")])
+@pytest.mark.parametrize("d,filt", [(16, "1"), (8, "1"), (24, "1"), (64, "1"), (16, "0")])
 def test_large_corpus_filter_path_vs_oracle(d, filt, monkeypatch):
     """Above 40 000 rows the search runs behind the float32 matrix-core filter (subset thresholds, MFMA scan, exact
     fp64 refinement of the kept candidates); lists and fp64 keys must equal the oracle's, as without the filter --

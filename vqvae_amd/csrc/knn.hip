@@ -381,7 +381,7 @@ bool filter_applies(int64_t n, int dp) {
     if (const char *e = getenv("GEO_KNN_FILTER")) {
         if (atoi(e) == 0) return false;
     }
-    return n >= 40000 && (dp == 8 || dp == 16 || dp == 32);
+    return n >= 40000 && (dp == 8 || dp == 16 || dp == 32 || dp == 64);
 }
 
 }  // namespace
@@ -452,7 +452,8 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
         if (p.dp == 8) knn_scan_kernel<8><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 16) knn_scan_kernel<16><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
-        else knn_scan_kernel<32><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else if (p.dp == 32) knn_scan_kernel<32><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else knn_scan_kernel<64><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         GEO_LAUNCH_CHECK();
         const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
 #define GEO_REFINE(DCHV, EXV) \
