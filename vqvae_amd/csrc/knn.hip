@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
 // 3. knn_refine_kernel: the kept candidates are re-evaluated with the same fp64 fma chains as knn_kernel and ranked
 //    by (distance, index): the result is the one knn_kernel gives.  A query whose list overflows FILTER_CAP (heavily
 //    duplicated points) is reported and the caller falls back to knn_kernel.
-constexpr int FILTER_STRIDE = 16, FILTER_CAP = 1024, SCAN_CT = 128;      // candidates staged per LDS tile
+constexpr int FILTER_STRIDE = 16, FILTER_CAP = 1024;
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void knn_subset_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void knn_tau_kernel(const double *__restrict__
     }
 }
 
-template <int DP>
+template <int DP, int SCAN_CT>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
                                                       const double *__restrict__ u, int64_t n, int64_t row0, int64_t rows,
                                                       double eps, int splits, int32_t *__restrict__ cnt,
@@ -234,6 +234,23 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
             Bs[buf][threadIdx.x >> 5][KI - 1][32 + (threadIdx.x & 31)] = 1.0f;
         }
     };
+    constexpr int EQ_CAP = 128;
+    __shared__ unsigned long long eb[4][EQ_CAP];
+    __shared__ int ec[4];
+    if (lane == 0) ec[wave] = 0;
+    auto flush = [&]() {                                       // wave-uniform call
+        const int m = ec[wave] < EQ_CAP ? ec[wave] : EQ_CAP;
+        for (int i = lane; i < m; i += 64) {
+            const unsigned long long e = eb[wave][i];
+            const int64_t row = (int64_t)(e >> 32);
+            const int32_t slot = atomicAdd(&cnt[row], 1);
+            if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = (int32_t)(e & 0xffffffffu);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ec[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
     fetch(tile_lo);
     put((int)(tile_lo & 1));
     __syncthreads();
@@ -254,6 +271,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
 #pragma unroll
             for (int q = 0; q < 16; ++q) { any0 |= __float_as_uint(acc0[q]); any1 |= __float_as_uint(acc1[q]); }
             if ((any0 | any1) & 0x80000000u) {
+                // kept pairs go to a per-wave LDS queue first: the returning global atomic that reserves a list slot
+                // costs microseconds, too much inside the MFMA stream; the queue is flushed 64 entries at a time
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int32_t cand = (int32_t)(tile * SCAN_CT + (t + tt) * 32 + r);
@@ -261,16 +280,25 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
                     for (int q = 0; q < 16; ++q) {
                         if ((tt ? acc1[q] : acc0[q]) < 0.0f) {
                             const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
-                            const int32_t slot = atomicAdd(&cnt[row], 1);
-                            if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                            const int pos = atomicAdd(&ec[wave], 1);
+                            if (pos < EQ_CAP) {
+                                eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
+                            } else {                               // queue full (masses of duplicates): straight to the list
+                                const int32_t slot = atomicAdd(&cnt[row], 1);
+                                if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                            }
                         }
                     }
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (ec[wave] >= EQ_CAP / 2) flush();
         if (tile + 1 < n_tiles) put(buf ^ 1);
         __syncthreads();
     }
+    flush();
 }
 
 // one wave per query: exact fp64 distances of its kept candidates (same fma chains as knn_kernel) into LDS, then the
@@ -452,10 +480,10 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         GEO_LAUNCH_CHECK();
         const int splits = (int)((int64_t)16384 / ((rows + 127) / 128) > 1 ? ((int64_t)16384 / ((rows + 127) / 128) > 64 ? 64 : (int64_t)16384 / ((rows + 127) / 128)) : 1);
         const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
-        if (p.dp == 8) knn_scan_kernel<8><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
-        else if (p.dp == 16) knn_scan_kernel<16><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
-        else if (p.dp == 32) knn_scan_kernel<32><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
-        else knn_scan_kernel<64><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        if (p.dp == 8) knn_scan_kernel<8, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else if (p.dp == 16) knn_scan_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else if (p.dp == 32) knn_scan_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        else knn_scan_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         GEO_LAUNCH_CHECK();
         const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
 #define GEO_REFINE(DCHV, EXV) \
