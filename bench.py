@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- latents/s through the geodesic-codebook hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU
+under torch.distributed.run, RCCL backend) BEFORE this process touches the GPU, and relays rank 0's JSON line.
 
 One step = one pass of the hot path over one batch of synthetic latents already resident in HBM
 (BASELINE.json configs[1]: 60 000 latents, d=16, k=20, K=512, FashionMNIST-shaped decoder with
@@ -42,12 +45,16 @@ WORKLOADS = {
     # name: (n_latents, d, out_channels, image_size, k, K)
     "c1": (2048, 16, 1, 28, 20, 64),
     "c2": (60000, 16, 1, 28, 20, 512),
-    "c3": (50000, 32, 3, 32, 20, 512),
+    "c3": (50000, 64, 3, 32, 20, 512),          # BASELINE config 3 as stated: d=64, 32-px decoder
+    "c3d32": (50000, 32, 3, 32, 20, 512),       # the reference's shipped CIFAR config (latent_dim 32)
+    "c4": (1000000, 16, 1, 28, 20, 1024),       # BASELINE config 4's workload (any number of GPUs)
     # second latent distribution -- noisy 2-D swiss roll embedded in d dims (long geodesics,
     # many relaxation sweeps); same decoder / k / K as c2
     "swiss": (60000, 16, 1, 28, 20, 512),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak = half the 157.3 TFLOP/s f32 vector peak of MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3
 
 
 def cpu_model():
@@ -114,6 +121,7 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
 
     dmin, arg = sharded_assign(len(res["medoids"]), solve)
     ms, launches = np.array([prof.get("ms", 0.0)]), np.array([prof.get("launches", 0)])
+    res["sharded"]["assign"] = world > 1
     res["sources_this_rank"] = prof.get("sources", 0)
     res["sweep_kernel"] = prof.get("kernel", "sweep_multi_kernel")
     torch.cuda.synchronize(z.device)
@@ -122,17 +130,19 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
     return res, (float(ms[0]), int(launches[0]))
 
 
-def cpu_baseline(res, z, dec, cfg):
-    """The oracle (CPU restatement, validated against the reference in the build container) timed on this
-    host on a bounded sample and scaled to the full workload with the reference's solve count (3K-1)."""
-    from oracle import _clib, metric as om, sssp as osp
+def cpu_baseline(res, z, dec, cfg, full):
+    """The oracle (CPU restatement, validated against the reference in the build container) timed on this host.
+    full=True: every stage of the workload is run in full with the reference's solve count (k++ K-1, assignment K,
+    QE K single-thread heap-Dijkstra solves).  full=False (large workloads): a bounded sample of every stage,
+    scaled, and labelled as such."""
+    from oracle import _clib, kmedoids as ok, metric as om, sssp as osp
     import ctypes
     n, d, K = cfg["n"], cfg["d"], cfg["K"]
     cores = host_cores()
     torch.set_num_threads(cores)
     zh = np.ascontiguousarray(z.cpu().numpy())
     lib = _clib.lib()
-    rows = min(n, 6000)
+    rows = n if full else min(n, 6000)
     idx = np.empty((rows, cfg["k"] + 1), np.int64)
     d2 = np.empty((rows, cfg["k"] + 1), np.float64)
     t0 = time.perf_counter()
@@ -141,24 +151,52 @@ def cpu_baseline(res, z, dec, cfg):
     t_knn = (time.perf_counter() - t0) * n / rows
     src, dst = (t.cpu().numpy() for t in res["edges"])
     E = len(src)
-    e_s = min(E, 8192)
+    e_s = E if full else min(E, 8192)
     sd = {k_: v.detach().cpu() for k_, v in dec.state_dict().items()}
     t0 = time.perf_counter()
     om.edge_lengths(sd, "batch", cfg["size"], zh[src[:e_s]], zh[dst[:e_s]], batch_size=512, training=True)
     t_jvp = (time.perf_counter() - t0) * E / e_s
     W = res["W_lcc"].to_scipy()
-    n_src = 24
-    t0 = time.perf_counter()
-    osp.dijkstra_multi_source(W, res["medoids"][:n_src])
-    t_solve = (time.perf_counter() - t0) / min(n_src, len(res["medoids"]))
-    t_kmed = t_solve * (3 * K - 1)
+    n_solves = 3 * K - 1
+    if full:
+        t0 = time.perf_counter()
+        med, assign, qe = ok.fit_kmedoids_optimized(W, K=K, init="kpp", seed=42)      # the reference's three stages
+        t_kmed = time.perf_counter() - t0
+        agree = bool(np.array_equal(med, res["medoids"]) and qe == res["qe"])
+        sample = (f"full: oracle port on host, kNN {n} rows (OpenMP, {cores} threads), JVP {E} edges (torch CPU, "
+                  f"{cores} threads), k-medoids {n_solves} heap-Dijkstra solves (1 thread, as scipy in the reference); "
+                  f"port medoids/QE equal the GPU's: {agree}")
+    else:
+        n_src = 24
+        t0 = time.perf_counter()
+        osp.dijkstra_multi_source(W, res["medoids"][:n_src])
+        t_kmed = (time.perf_counter() - t0) / min(n_src, len(res["medoids"])) * n_solves
+        sample = (f"EXTRAPOLATED from a sample: kNN {rows}/{n} query rows x{n / rows:.0f}, JVP {e_s}/{E} edges "
+                  f"x{E / e_s:.0f} (torch CPU, {cores} threads), Dijkstra {n_src} sources x{n_solves / n_src:.0f} "
+                  f"(reference runs 3K-1 = {n_solves} single-thread solves)")
     total = t_knn + t_jvp + t_kmed
     return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "host_logical_cpus": os.cpu_count(),
-            "sample": (f"oracle on host: kNN {rows}/{n} query rows x{n / rows:.0f}, JVP {e_s}/{E} edges x{E / e_s:.0f} "
-                       f"(torch CPU, {cores} threads), Dijkstra {n_src} sources x{(3 * K - 1) / n_src:.0f} "
-                       f"(reference runs 3K-1 = {3 * K - 1} single-thread solves)"),
+            "host_logical_cpus": os.cpu_count(), "sample": sample,
             "stages_s": {"knn": round(t_knn, 3), "jvp": round(t_jvp, 3), "kmedoids": round(t_kmed, 3)}}
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """--gpus N without a launcher: start N rank processes under torch.distributed.run (this process has not
+    touched the GPU and never will) and relay their output; returns the exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--workload", args.workload] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -170,16 +208,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        n_dev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+        if n_dev < args.gpus and os.environ.get("GEO_BENCH_BACKEND", "nccl") == "nccl":
+            log(f"bench.py: --gpus {args.gpus} but {n_dev} GPU(s) visible (set GEO_BENCH_BACKEND=gloo to rehearse the "
+                f"{args.gpus}-rank path on fewer devices)")
+            sys.exit(2)
+        sys.exit(launch_ranks(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GEO_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
+        backend = os.environ.get("GEO_BENCH_BACKEND", "nccl")      # "gloo" lets ranks rehearse on fewer GPUs
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -216,14 +265,26 @@ def main():
     sweep_ms, launches = prof
     algo_bytes = res["sources_this_rank"] * (16.0 * nnz + 16.0 * n)    # B_sssp x sources solved on this rank
     achieved = algo_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    traffic = None                                      # PMC-derived bytes per launch: measured for c2 on one GPU only
+    # PMC-derived bytes per launch are NOT measured in this run (counters need their own rocprofv3 --pmc passes):
+    # the committed summary of the stated PMC run is quoted, for the same kernel and workload only
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.workload == "c2" and world == 1:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("kernel") == res["sweep_kernel"]:
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/traffic_latest.json (separate rocprofv3 --pmc passes, run {tj.get('tag', '?')}); not measured in this run"
     ms_per_step = elapsed / args.steps * 1e3
+    stages_ms = {k_: v * 1e3 / args.steps for k_, v in timers.items()}
+    sharded = res.get("sharded", {})
+    if world > 1:
+        parts = [name for name, on in (("kNN query rows", sharded.get("knn")), ("JVP chunks", sharded.get("jvp")),
+                                       ("assignment sources", sharded.get("assign"))) if on]
+        parallelism = (f"{world} ranks over {backend}: " + (" + ".join(parts) + " sharded (all-gather merges)" if parts else "nothing sharded")
+                       + "; k-means++ chain replicated")
+    else:
+        parallelism = "1 gpu"
     out = {
         "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] / (elapsed / args.steps),
         "unit": "latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,20 +293,33 @@ def main():
         "config": {"workload": f"{args.workload}: N={cfg['n']} latents d={cfg['d']} k={cfg['k']} K={cfg['K']} "
                                f"{cfg['size']}px decoder BN-train batch 512 sym=union init=kpp seed=42",
                    "graph": {"nodes": n, "nnz": nnz, "edges_reweighted": res["n_edges"]},
-                   "parallelism": (f"{world} ranks: kNN rows + JVP chunks + assignment sources sharded (RCCL all-gather), "
-                                   f"k++ chain replicated") if world > 1 else "1 gpu"},
+                   "parallelism": parallelism},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": res["sweep_kernel"], "launches_per_step": launches,
                      "avg_launch_ms": sweep_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, launches)},
-        "stages_ms": {k_: v * 1e3 / args.steps for k_, v in timers.items()},
+        "stages_ms": stages_ms,
         "parity_selfcheck": {"batched_assign_equals_fused": same, "qe": res["qe"]},
     }
+    # compute-bound stages: kNN as 2*N^2*d flop vs the fp64 vector peak, JVP as 3.47 MFLOP/edge vs the
+    # f32-MFMA peak; stage wall time (whole stage incl. graph assembly / BN statistics), this rank's share of the work
+    share = 1.0 / world
+    if stages_ms.get("knn"):
+        fl = 2.0 * cfg["n"] ** 2 * cfg["d"] * share
+        out["roofline_knn"] = {"bound": "fp64-valu", "achieved": fl / (stages_ms["knn"] * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": fl / (stages_ms["knn"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                               "model": "2*N^2*d flop / kNN stage time (search + symmetrise + edge list)"}
+    if stages_ms.get("jvp"):
+        fl = 3.47e6 * res["n_edges"] * share
+        out["roofline_jvp"] = {"bound": "mfma-f32", "achieved": fl / (stages_ms["jvp"] * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": fl / (stages_ms["jvp"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                               "model": "3.47 MFLOP/edge (SURVEY 8d, 28-px decoder) / JVP stage time"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            full = args.workload in ("c1", "c2") and os.environ.get("GEO_BENCH_CPU_SAMPLE", "0") != "1"
             with contextlib.redirect_stdout(sys.stderr):
-                out["cpu_baseline"] = cpu_baseline(res, z, dec, cfg)
+                out["cpu_baseline"] = cpu_baseline(res, z, dec, cfg, full)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

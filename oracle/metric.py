@@ -28,11 +28,14 @@ def group_count(channels: int) -> int:
     return g
 
 
+_DEVICE = "cpu"     # where the restatement runs; edge_lengths(device=...) may move the CHECKER to the GPU (fp64 torch)
+
+
 def _t(sd: Mapping, key: str, dtype):
     v = sd[key]
     if not torch.is_tensor(v):
         v = torch.from_numpy(np.asarray(v))
-    return v.detach().to("cpu", dtype)
+    return v.detach().to(_DEVICE, dtype)
 
 
 def _norm_push(x, t, sd, prefix, norm_type, training, dtype):
@@ -79,8 +82,8 @@ def jvp_norms(sd: Mapping, norm_type: str, output_image_size: int, z, delta, tra
     if norm_type not in ("batch", "group"):
         norm_type = "none"
     pad_last = {28: 3, 32: 1}[int(output_image_size)]
-    z = torch.as_tensor(z).to(dtype)
-    delta = torch.as_tensor(delta).to(dtype)
+    z = torch.as_tensor(z).to(_DEVICE, dtype)
+    delta = torch.as_tensor(delta).to(_DEVICE, dtype)
     x = z.view(z.shape[0], -1, 1, 1)
     t = delta.view(delta.shape[0], -1, 1, 1)
     w = _t(sd, "conv_in.weight", dtype)
@@ -102,22 +105,30 @@ def jvp_norms(sd: Mapping, norm_type: str, output_image_size: int, z, delta, tra
 
 
 def edge_lengths(sd: Mapping, norm_type: str, output_image_size: int, z_start, z_end, batch_size: int = 512,
-                 training: bool = True, dtype=torch.float32) -> torch.Tensor:
-    """riemannian_metric.py:37-66: 0.5*(|J(z_i)δ| + |J(z_j)δ|), chunked exactly like the reference."""
-    z_start = torch.as_tensor(z_start).to(dtype)
-    z_end = torch.as_tensor(z_end).to(dtype)
-    assert z_start.shape == z_end.shape, "Start and end points must have same shape"
-    delta = z_end - z_start
-    out = []
-    with torch.no_grad():
-        for lo in range(0, z_start.shape[0], batch_size):
-            hi = min(lo + batch_size, z_start.shape[0])
-            a = jvp_norms(sd, norm_type, output_image_size, z_start[lo:hi], delta[lo:hi], training, dtype)
-            b = jvp_norms(sd, norm_type, output_image_size, z_end[lo:hi], delta[lo:hi], training, dtype)
-            out.append(0.5 * (a + b))
-    if not out:
-        return torch.empty(0, dtype=torch.float32)
-    return torch.cat(out).to(torch.float32)
+                 training: bool = True, dtype=torch.float32, device: str = "cpu") -> torch.Tensor:
+    """riemannian_metric.py:37-66: 0.5*(|J(z_i)δ| + |J(z_j)δ|), chunked exactly like the reference.
+    `device` lets a full-size GPU test run this same closed form in fp64 torch on the GPU (a torch reference of
+    the floating-point kernel, tied to the CPU run on sample chunks by the test); the result returns to the CPU."""
+    global _DEVICE
+    prev, _DEVICE = _DEVICE, device
+    try:
+        sd = {k: _t(sd, k, torch.float64 if k.endswith("num_batches_tracked") else dtype) for k in sd}
+        z_start = torch.as_tensor(z_start).to(device, dtype)
+        z_end = torch.as_tensor(z_end).to(device, dtype)
+        assert z_start.shape == z_end.shape, "Start and end points must have same shape"
+        delta = z_end - z_start
+        out = []
+        with torch.no_grad():
+            for lo in range(0, z_start.shape[0], batch_size):
+                hi = min(lo + batch_size, z_start.shape[0])
+                a = jvp_norms(sd, norm_type, output_image_size, z_start[lo:hi], delta[lo:hi], training, dtype)
+                b = jvp_norms(sd, norm_type, output_image_size, z_end[lo:hi], delta[lo:hi], training, dtype)
+                out.append(0.5 * (a + b))
+        if not out:
+            return torch.empty(0, dtype=torch.float32)
+        return torch.cat(out).to("cpu", torch.float32)
+    finally:
+        _DEVICE = prev
 
 
 def make_decoder_state(seed: int, latent_dim: int, out_channels: int, channels=(256, 128, 64),

@@ -54,6 +54,9 @@ def _worker(rank, world, port, out_dir):
         lo, hi = par.block_range(len(z), rank, world)
         z_full = par.gather_latents(zt[lo:hi], len(z))
         idx, d2 = par.sharded_knn(z_full, 7, search)
+        idx_c, d2_later = par.sharded_knn(z_full, 7, search, gather_d2=False)    # connectivity graphs: no fp64 gather ...
+        assert torch.equal(idx_c, idx) and callable(d2_later)
+        assert torch.equal(d2_later(), d2)                                        # ... unless asked for (collective)
 
         def lengths(e0, e1):
             return om.edge_lengths(sd, "batch", 28, z[src[e0:e1]], z[dst[e0:e1]], batch_size=64, training=True)

@@ -1,6 +1,15 @@
-"""Parity at BASELINE.json's full single-GPU size (config C2: 60 000 latents, d=16, k=20, K=512) through
-oracle spot checks and size-independent properties: the oracle is too slow to redo the whole
-workload, so it checks samples and the rest is covered by invariants."""
+"""Parity at BASELINE.json's full sizes on the MI355X.
+
+C2 (60 000 latents, d=16, k=20, K=512): the whole k-means++ chain / assignment / QE against the oracle's
+single-pass chain on the GPU's own graph (all 512 medoids, all 60 000 assignments), every BatchNorm chunk of
+the JVP against the fp64 closed form, the reference's own C2 results (tests/golden/c2_formula.npz: reference
+fit_kmedoids_optimized on formula weights; tests/golden/c2_cli.npz: the reference CLI end to end).
+C3 as BASELINE states it (50 000 latents, d=64, 32-px decoder, K=512) and C4 on one GPU (1 M latents, K=1024).
+"""
+import ctypes
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -8,96 +17,259 @@ import torch
 pytestmark = pytest.mark.gpu
 
 N, D, KNN, KMED = 60000, 16, 20, 512
+TOL = 1e-5                       # edge lengths within 1e-5 relative ...
+GATE = 0.999                     # ... for >= 99.9 % of the edges
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(name, payload):
+    """Measured (not asserted) quantities, kept for DESIGN.md: gpurun_out/parity_<name>.json."""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+        json.dump(payload, f, indent=1)
+    print(name, json.dumps(payload))
+
+
+def _decoder(sd, d, cout, size):
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    dec = SpatialDecoder(cout, (256, 128, 64), d, size, "batch")
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return dec
+
+
+def _pipeline(n, d, cout, size, K):
+    from oracle import metric as om
+    from oracle import synthetic as syn
+    from vqvae_amd._device import device
+    from vqvae_amd.scripts.build_codebook import build_codebook_device
+    dev = device()
+    z_h = syn.gauss_latents(n, d, 0)
+    sd = om.make_decoder_state(0, d, cout, norm_type="batch")
+    z = torch.from_numpy(z_h).to(dev)
+    res = build_codebook_device(z, _decoder(sd, d, cout, size).to(dev).train(), k=KNN, sym="union", K=K, init="kpp",
+                                seed=42, batch_size=512)
+    return {"z": z, "z_h": z_h, "sd": sd, "res": res, "dev": dev, "size": size}
 
 
 @pytest.fixture(scope="module")
 def c2():
-    from oracle import metric as om
-    from vqvae_amd._device import device
-    from vqvae_amd.scripts.build_codebook import build_codebook_device
-    from vqvae_amd.spatial_decoder import SpatialDecoder
-    dev = device()
-    z_h = np.random.RandomState(0).randn(N, D).astype(np.float32)
-    sd = om.make_decoder_state(0, D, 1, norm_type="batch")
-    dec = SpatialDecoder(1, (256, 128, 64), D, 28, "batch")
-    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    z = torch.from_numpy(z_h).to(dev)
-    res = build_codebook_device(z, dec.to(dev).train(), k=KNN, sym="union", K=KMED, init="kpp", seed=42, batch_size=512)
-    return {"z": z, "z_h": z_h, "sd": sd, "res": res, "dev": dev}
+    return _pipeline(N, D, 1, 28, KMED)
 
 
-def test_knn_rows_vs_oracle_and_graph_invariants(c2):
-    import ctypes
+def _columns_strictly_ascending(W):
+    d = np.diff(W.indices.astype(np.int64))
+    inside = np.ones(len(d), dtype=bool)
+    ends = W.indptr[1:-1]
+    inside[ends[(ends > 0) & (ends < W.nnz)] - 1] = False       # differences that straddle two rows
+    return bool((d[inside] > 0).all())
+
+
+def _knn_rows_vs_oracle(ctx, n, d, spans):
     from oracle import _clib
     from vqvae_amd.geo.knn_graph_optimized import knn_search_device
-    rows = np.concatenate([np.arange(0, 64), np.arange(29968, 30032), np.arange(N - 64, N)])
-    idx, d2 = knn_search_device(c2["z"], KNN + 1)
+    idx, d2 = knn_search_device(ctx["z"], KNN + 1)
     idx_h, d2_h = idx.cpu().numpy(), d2.cpu().numpy()
-    for r0, r1 in ((0, 64), (29968, 30032), (N - 64, N)):
+    for r0, r1 in spans:
         io = np.empty((r1 - r0, KNN + 1), np.int64)
         do = np.empty((r1 - r0, KNN + 1), np.float64)
-        _clib.lib().oracle_knn(ctypes.c_void_p(c2["z_h"].ctypes.data), N, D, KNN + 1, 1, r0, r1,
+        _clib.lib().oracle_knn(ctypes.c_void_p(ctx["z_h"].ctypes.data), n, d, KNN + 1, 1, r0, r1,
                                ctypes.c_void_p(io.ctypes.data), ctypes.c_void_p(do.ctypes.data))
         np.testing.assert_array_equal(idx_h[r0:r1], io)
         np.testing.assert_array_equal(d2_h[r0:r1], do)          # same fma chains -> bit-equal fp64 keys
-    assert (idx_h[:, 0] == np.arange(N)).all() and (d2_h[:, 0] == 0).all()
+    assert (idx_h[:, 0] == np.arange(n)).all() and (d2_h[:, 0] == 0).all()
     assert (np.diff(d2_h, axis=1) >= 0).all()                   # sorted
-    W = c2["res"]["W_lcc"].to_scipy()
-    assert W.shape == (N, N) and (W - W.T).nnz == 0 and W.diagonal().sum() == 0
-    assert W.has_sorted_indices or (np.diff(W.indices) > 0)[np.diff(W.indptr).cumsum()[:-1] - 1].all() or True
-    deg = np.diff(W.indptr)
-    assert deg.min() >= KNN and c2["res"]["n_edges"] * 2 == W.nnz
 
 
-def test_edge_lengths_sample_vs_oracle(c2):
+def _graph_invariants(ctx, n):
+    W = ctx["res"]["W_lcc"].to_scipy()
+    assert W.shape == (n, n) and (W - W.T).nnz == 0 and W.diagonal().sum() == 0
+    assert _columns_strictly_ascending(W)                        # canonical CSR
+    assert np.diff(W.indptr).min() >= KNN and ctx["res"]["n_edges"] * 2 == W.nnz
+    return W
+
+
+def _all_chunks_vs_fp64(ctx, name):
+    """EVERY BatchNorm chunk against the fp64 closed form (oracle/metric.py run in fp64 torch on the GPU, tied to
+    its CPU run on three chunks); returns the per-edge relative errors."""
     from oracle import metric as om
-    src, dst = (t.cpu().numpy() for t in c2["res"]["edges"])
-    L = c2["res"]["edge_lengths"].cpu().numpy()
+    src, dst = (t.cpu().numpy() for t in ctx["res"]["edges"])
+    L = ctx["res"]["edge_lengths"].cpu().numpy()
     assert L.shape == src.shape and np.isfinite(L).all() and (L > 0).all()
     assert (src < dst).all() and (np.diff(src) >= 0).all()       # row-major upper triangle
-    # gate = the fp64 closed form: the float32 restatement itself drifts by up to 1e-3 on batches
-    # with |mean| >> std (chunk 0: 17 distinct start points; chunk 917), where the kernels' fp64 batch
-    # statistics stay within 5e-7 of the fp64 result -- as the reference does (torch CPU accumulates in double)
-    for c in (0, 917, len(src) // 512 - 1):                      # three whole BatchNorm chunks
-        sl = slice(c * 512, (c + 1) * 512)
-        ref64 = om.edge_lengths(c2["sd"], "batch", 28, c2["z_h"][src[sl]], c2["z_h"][dst[sl]], batch_size=512,
-                                training=True, dtype=torch.float64).numpy()
-        rel = np.abs(L[sl] - ref64) / ref64
-        assert np.mean(rel <= 1e-5) >= 0.998 and np.quantile(rel, 0.99) < 2e-6, (c, rel.max())
-        ref32 = om.edge_lengths(c2["sd"], "batch", 28, c2["z_h"][src[sl]], c2["z_h"][dst[sl]], batch_size=512,
-                                training=True).numpy()
-        assert np.mean(np.abs(L[sl] - ref32) / ref32 <= 1e-5) >= 0.97, c
-    tail = slice((len(src) // 512) * 512, len(src))             # ragged last chunk
-    ref = om.edge_lengths(c2["sd"], "batch", 28, c2["z_h"][src[tail]], c2["z_h"][dst[tail]], batch_size=512,
-                          training=True, dtype=torch.float64).numpy()
-    assert np.mean(np.abs(L[tail] - ref) / ref <= 1e-5) >= 0.99
+    zs, ze = ctx["z_h"][src], ctx["z_h"][dst]
+    ref64 = om.edge_lengths(ctx["sd"], "batch", ctx["size"], zs, ze, batch_size=512, training=True,
+                            dtype=torch.float64, device="cuda").numpy()
+    n_chunks = (len(src) + 511) // 512
+    for c in (0, min(917, n_chunks - 2), n_chunks - 1):          # the checker itself: GPU fp64 == CPU fp64
+        sl = slice(c * 512, min((c + 1) * 512, len(src)))
+        cpu64 = om.edge_lengths(ctx["sd"], "batch", ctx["size"], zs[sl], ze[sl], batch_size=512, training=True,
+                                dtype=torch.float64).numpy()
+        np.testing.assert_allclose(ref64[sl], cpu64, rtol=2e-6)  # both are f32-rounded fp64 results
+    rel = np.abs(L - ref64) / ref64
+    worst_chunk = max(np.mean(rel[c * 512:(c + 1) * 512] > TOL) for c in range(n_chunks))
+    _record(f"{name}_jvp_vs_fp64", {"edges": int(len(L)), "chunks": int(n_chunks), "edges_over_1e-5": int((rel > TOL).sum()),
+                                    "frac_within": float(np.mean(rel <= TOL)), "p99": float(np.quantile(rel, 0.99)),
+                                    "max_rel": float(rel.max()), "worst_chunk_frac_over": float(worst_chunk)})
+    assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
+    assert np.quantile(rel, 0.99) < 2e-6
+    return rel
 
 
-def test_codebook_vs_oracle_solves_and_invariants(c2):
+def _full_chain_vs_oracle(ctx, K):
+    """The oracle's single-pass chain (K heap-Dijkstra solves + numpy draws) on the GPU's own graph: every medoid,
+    every assignment and QE must be equal."""
+    from oracle import kmedoids as ok
+    res = ctx["res"]
+    W = res["W_lcc"].to_scipy()
+    med_o, assign_o, qe_o = ok.fit_kmedoids_single_pass(W, K=K, seed=42)
+    np.testing.assert_array_equal(res["medoids"], med_o)
+    np.testing.assert_array_equal(res["assign_flat"][res["mask_lcc"]], assign_o)
+    assert res["qe"] == qe_o
+    return W
+
+
+# ------------------------------------------------------------------------------------------------- C2
+def test_c2_knn_rows_vs_oracle_and_graph_invariants(c2, golden):
+    from oracle import synthetic as syn
+    _knn_rows_vs_oracle(c2, N, D, ((0, 64), (29968, 30032), (N - 64, N)))
+    W = _graph_invariants(c2, N)
+    g = golden("c2_formula")                                     # the reference's (sklearn) structure at C2
+    assert W.nnz == int(g["meta"][5])
+    np.testing.assert_array_equal(syn.digest(W.indptr.astype(np.int32)), g["indptr_sha256"])
+    np.testing.assert_array_equal(syn.digest(W.indices.astype(np.int32)), g["indices_sha256"])
+
+
+def test_c2_every_bn_chunk_vs_fp64_closed_form(c2):
+    _all_chunks_vs_fp64(c2, "c2")
+
+
+def test_c2_edge_lengths_vs_reference_cli_sample(c2, golden):
+    """The reference CLI's own f32 edge lengths at C2 (33 whole chunks incl. the ill-conditioned 0 and 917, and the tail)."""
+    g = golden("c2_cli")
+    L = c2["res"]["edge_lengths"].cpu().numpy()
+    assert len(L) == int(g["meta"][6])
+    got = np.concatenate([L[c * 512:(c + 1) * 512] for c in g["sample_chunks"]])
+    ref = g["sample_lengths"]
+    rel = np.abs(got - ref) / ref
+    _record("c2_jvp_vs_reference_sample", {"edges": int(len(ref)), "frac_within": float(np.mean(rel <= TOL)),
+                                           "p99": float(np.quantile(rel, 0.99)), "max_rel": float(rel.max()),
+                                           "bit_equal_frac": float(np.mean(got == ref))})
+    assert np.mean(rel <= TOL) >= GATE, rel.max()
+    assert abs(float(L.astype(np.float64).sum()) / float(g["lengths_sum"]) - 1.0) < 1e-6
+
+
+def test_c2_full_chain_vs_oracle_and_dense_matrix(c2):
     from oracle import kmedoids as ok
     from oracle import sssp as osp
     from vqvae_amd.geo.geo_shortest_paths import sssp_multi_device
     res = c2["res"]
-    W = res["W_lcc"].to_scipy()
+    W = _full_chain_vs_oracle(c2, KMED)
     med, assign = res["medoids"], res["assign_flat"]
-    assert len(set(med.tolist())) == KMED and (assign >= 0).all() and (assign < KMED).all()
-    assert (assign[med] == np.arange(KMED)).all()                # every medoid is assigned to itself
-    # oracle Dijkstra from a sample of medoids: the GPU's batched matrix rows are bit-identical
-    sample = [0, 1, 255, 511]
+    assert len(set(med.tolist())) == KMED and (assign[med] == np.arange(KMED)).all()
     Dg, _, dmin, arg, _ = sssp_multi_device(res["W_lcc"], torch.from_numpy(med.astype(np.int32)).to(c2["dev"]),
                                             want_D=True, want_min=True)
     Dg = Dg.cpu().numpy()
-    Do = osp.dijkstra_multi_source(W, med[sample])
-    np.testing.assert_array_equal(Dg[sample], Do)
+    sample = list(range(0, KMED, 16)) + [1, 255, 511]            # 35 of the 512 rows against heap Dijkstra
+    np.testing.assert_array_equal(Dg[sample], osp.dijkstra_multi_source(W, med[sample]))
     # the fused chain's assignment/QE equal the dense matrix's argmin/min (reference stages 2 and 3)
     np.testing.assert_array_equal(Dg.argmin(axis=0), assign)
     np.testing.assert_array_equal(arg.cpu().numpy(), assign)
     np.testing.assert_array_equal(dmin.cpu().numpy(), Dg.min(axis=0))
     assert res["qe"] == ok.quantization_error_from(Dg.min(axis=0))
-    # first draws of the chain re-derived with the oracle's host-side numpy draw on the oracle's own solves
-    centers = ok.kpp_initialization_graph(W, 6, seed=42)
-    assert centers == med[:6].tolist()
-    # metric sanity on the sampled rows: symmetry (to fp rounding) and triangle inequality through medoids
-    assert np.allclose(Do[:, med[sample]], Do[:, med[sample]].T, rtol=1e-6)
-    i, j = 0, 2
-    assert (Do[i] <= Do[i][med[sample[j]]] + Do[j] + 1e-4).all()
+
+
+def test_c2_kmedoids_vs_reference_on_formula_weights(c2, golden):
+    """Same W as the reference (its own kNN structure, bit-reproducible weights) -> the reference's medoids, all 60 000
+    assignments and QE, bit for bit (tests/golden/c2_formula.npz, generated by oracle/gen_golden_c2.py)."""
+    from oracle import synthetic as syn
+    from vqvae_amd._device import DeviceCSR
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
+    g = golden("c2_formula")
+    G = c2["res"]["W_lcc"]
+    rows = np.repeat(np.arange(N), np.diff(G.indptr.cpu().numpy()))
+    w = syn.formula_weights(rows, G.indices.cpu().numpy())
+    Gf = DeviceCSR(G.n, G.indptr, G.indices, torch.from_numpy(w).to(c2["dev"]))
+    med, assign, qe = fit_kmedoids_optimized(Gf, K=KMED, init="kpp", seed=42)
+    np.testing.assert_array_equal(med, g["medoids"])
+    np.testing.assert_array_equal(assign, g["assign"].astype(int))
+    assert qe == float(g["qe"])
+
+
+def test_c2_end_to_end_vs_reference_cli_measured(c2, golden):
+    """North-star check at the headline size: codes / medoids of the GPU pipeline against the reference CLI's.
+    The graph structure must be identical.  The 511 D^2 draws see edge weights that agree with the reference's only to
+    float32 rounding of a different (equally valid) operation order, so identity of the drawn centres is MEASURED and
+    recorded here, not assumed (DESIGN.md section 2 states the result); the first centre (randint) must agree."""
+    from oracle import synthetic as syn
+    g = golden("c2_cli")
+    res = c2["res"]
+    W = res["W_lcc"].to_scipy()
+    np.testing.assert_array_equal(syn.digest(W.indptr.astype(np.int32)), g["indptr_sha256"])
+    np.testing.assert_array_equal(syn.digest(W.indices.astype(np.int32)), g["indices_sha256"])
+    med_ref, codes_ref = g["medoid_indices"], g["codes"].astype(np.int32).reshape(-1)
+    same = res["medoids"] == med_ref
+    lead = int(np.argmin(same)) if not same.all() else len(same)
+    _record("c2_end_to_end_vs_reference", {"medoids_identical": bool(same.all()), "leading_identical_draws": lead,
+                                           "medoids_in_common": int(len(set(res["medoids"].tolist()) & set(med_ref.tolist()))),
+                                           "codes_identical_frac": float(np.mean(res["assign_flat"] == codes_ref))})
+    assert lead >= 1
+
+
+# ------------------------------------------------------------------------------------------------- C3
+@pytest.fixture(scope="module")
+def c3():
+    """BASELINE config 3 as stated: 50 000 latents, d=64, 32-px (CIFAR-shaped, 3-channel) decoder, K=512."""
+    return _pipeline(50000, 64, 3, 32, KMED)
+
+
+def test_c3_d64_knn_jvp_chain_vs_oracle(c3):
+    n = 50000
+    _knn_rows_vs_oracle(c3, n, 64, ((0, 48), (25000, 25048), (n - 48, n)))
+    _graph_invariants(c3, n)
+    _all_chunks_vs_fp64(c3, "c3")
+    _full_chain_vs_oracle(c3, KMED)
+
+
+# ------------------------------------------------------------------------------------------------- C4 on one GPU
+def test_c4_one_gpu_1m_latents_k1024():
+    """BASELINE config 4's workload on ONE GPU (the 8-GPU sharding is covered by the multi-rank tests): oracle rows
+    and draws on samples, invariants on the rest (the oracle chain at this size would take ~1 h)."""
+    from oracle import kmedoids as ok
+    from oracle import metric as om
+    from oracle import sssp as osp
+    from vqvae_amd._device import release_workspace
+    from vqvae_amd.geo.geo_shortest_paths import sssp_multi_device
+    n, K = 1_000_000, 1024
+    ctx = _pipeline(n, D, 1, 28, K)
+    res = ctx["res"]
+    _knn_rows_vs_oracle(ctx, n, D, ((0, 32), (n - 32, n)))
+    W = res["W_lcc"].to_scipy()
+    assert W.shape == (n, n) and _columns_strictly_ascending(W) and np.diff(W.indptr).min() >= KNN
+    assert res["n_edges"] * 2 == W.nnz
+    src, dst = (t.cpu().numpy() for t in res["edges"])
+    L = res["edge_lengths"].cpu().numpy()
+    assert np.isfinite(L).all() and (L > 0).all()
+    n_chunks = (len(src) + 511) // 512
+    for c in (0, n_chunks // 2, n_chunks - 1):
+        sl = slice(c * 512, min((c + 1) * 512, len(src)))
+        ref = om.edge_lengths(ctx["sd"], "batch", 28, ctx["z_h"][src[sl]], ctx["z_h"][dst[sl]], batch_size=512,
+                              training=True, dtype=torch.float64).numpy()
+        rel = np.abs(L[sl] - ref) / ref
+        assert np.mean(rel <= TOL) >= 0.995 and np.quantile(rel, 0.99) < 2e-6, (c, rel.max())
+    med, assign = res["medoids"], res["assign_flat"]
+    assert len(set(med.tolist())) == K and (assign >= 0).all() and (assign < K).all()
+    assert (assign[med] == np.arange(K)).all()
+    centers = ok.kpp_initialization_graph(W, 4, seed=42)         # the first draws on the oracle's own solves
+    assert centers == med[:4].tolist()
+    rows = [0, 3, 511, 1023]
+    Dg, _, dmin, arg, _ = sssp_multi_device(res["W_lcc"], torch.from_numpy(med[rows].astype(np.int32)).to(ctx["dev"]),
+                                            want_D=True, want_min=True)
+    np.testing.assert_array_equal(Dg.cpu().numpy(), osp.dijkstra_multi_source(W, med[rows]))
+    _, _, dmin, arg, _ = sssp_multi_device(res["W_lcc"], torch.from_numpy(med.astype(np.int32)).to(ctx["dev"]),
+                                           want_D=False, want_min=True)
+    np.testing.assert_array_equal(arg.cpu().numpy(), assign)     # the reference's assignment stage == fused chain
+    assert res["qe"] == ok.quantization_error_from(dmin.cpu().numpy())
+    del ctx, res
+    release_workspace()
+    torch.cuda.empty_cache()

@@ -214,4 +214,26 @@ def test_kpp_small_and_degenerate_graphs():
         np.testing.assert_array_equal(assign, ao)
         assert qe == qo or (np.isinf(qe) and np.isinf(qo))
         for i, m in enumerate(med):
-            assert assign[m] == i or qe == float("inf") or True
+            assert assign[m] == i                     # every medoid is its own nearest centre (positive weights)
+
+
+def test_repeated_uniform_fallbacks_follow_the_reference_stream(golden):
+    """Zero-weight cliques: draws degenerate (sum of weights == 0) several times in ONE chain, each taking the
+    reference's uniform fallback (kmeans_optimized.py:62-69), which consumes the RandomState stream differently from a
+    weighted draw.  Expected values are the reference's own outputs (tests/golden/kmedoids_zero.npz)."""
+    import os
+    from oracle import synthetic as syn
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
+    g = golden("kmedoids_zero")
+    for i, (sizes, K, seed) in enumerate(syn.ZERO_CASES):
+        W = syn.zero_clusters(sizes)
+        for host_draw in (False, True):
+            if host_draw:
+                os.environ["GEO_KPP_HOST_DRAW"] = "1"
+            try:
+                med, assign, qe = fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+            finally:
+                os.environ.pop("GEO_KPP_HOST_DRAW", None)
+            np.testing.assert_array_equal(med, g[f"case{i}/medoids"], err_msg=str((sizes, K, seed, host_draw)))
+            np.testing.assert_array_equal(assign, g[f"case{i}/assign"])
+            assert qe == float(g[f"case{i}/qe"])

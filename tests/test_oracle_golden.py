@@ -155,3 +155,49 @@ def test_pipeline_c1_equals_reference_cli(golden):
                         batch_size=512, training=True).numpy()
     ref = np.asarray(W[edges[:1024, 0], edges[:1024, 1]]).ravel()
     assert np.mean(np.abs(L - ref) / ref <= 1e-5) >= 0.998
+
+
+def test_zero_weight_fallback_chains_equal_reference(golden):
+    """Repeated uniform fallbacks in one chain (kmeans_optimized.py:62-69): the oracle follows the reference's
+    RandomState stream (tests/golden/kmedoids_zero.npz holds the reference's outputs)."""
+    from oracle import synthetic as syn
+    g = golden("kmedoids_zero")
+    for i, (sizes, K, seed) in enumerate(syn.ZERO_CASES):
+        W = syn.zero_clusters(sizes)
+        for fit in (ok.fit_kmedoids_optimized, lambda W, K, seed: ok.fit_kmedoids_single_pass(W, K=K, seed=seed)):
+            med, assign, qe = fit(W, K=K, seed=seed)
+            np.testing.assert_array_equal(med, g[f"case{i}/medoids"])
+            np.testing.assert_array_equal(assign, g[f"case{i}/assign"])
+            assert qe == float(g[f"case{i}/qe"])
+
+
+def test_cf64_edge_lengths_vs_reference(golden):
+    """latent_dim 64, 32-px decoder (BASELINE config 3 as stated): closed-form f32 oracle vs the reference's lengths."""
+    g = golden("metric_cf64")
+    d, cout, size, seed, zseed, E = (int(v) for v in g["cf64_batch/meta"])
+    sd = om.make_decoder_state(seed, d, cout, norm_type="batch")
+    r = np.random.RandomState(zseed)
+    zs = r.randn(E, d).astype(np.float32)
+    ze = (zs + 0.3 * r.randn(E, d)).astype(np.float32)
+    for training, bs in ((True, 512), (False, 100)):
+        L = om.edge_lengths(sd, "batch", size, zs, ze, batch_size=bs, training=training).numpy()
+        ref = g[f"cf64_batch/train{int(training)}/bs{bs}"]
+        rel = np.abs(L - ref) / ref
+        assert np.mean(rel <= 1e-5) >= 0.999 and np.quantile(rel, 0.99) < 2e-6, rel.max()
+
+
+def test_c2_fixture_structure_and_first_draws(golden):
+    """Full-size fixture (tests/golden/c2_formula.npz, reference outputs at N=60 000, K=512): the oracle's kNN structure
+    hashes to the reference's and its first k-means++ draws on the formula weights are the reference's (the whole
+    512-centre chain is compared on the GPU box, where the oracle's 512 solves take seconds)."""
+    from oracle import synthetic as syn
+    g = golden("c2_formula")
+    n, d, k, K, seed, nnz = (int(v) for v in g["meta"])
+    W, _ = okn.build_knn_graph_auto(syn.gauss_latents(n, d, 0), k=k, mode="connectivity", sym="union")
+    W.sort_indices()
+    assert W.nnz == nnz
+    np.testing.assert_array_equal(syn.digest(W.indptr.astype(np.int32)), g["indptr_sha256"])
+    np.testing.assert_array_equal(syn.digest(W.indices.astype(np.int32)), g["indices_sha256"])
+    rows = np.repeat(np.arange(n), np.diff(W.indptr))
+    Wf = sparse.csr_matrix((syn.formula_weights(rows, W.indices), W.indices, W.indptr), shape=(n, n))
+    assert ok.kpp_initialization_graph(Wf, 6, seed=seed) == g["medoids"][:6].tolist()

@@ -2,11 +2,13 @@
 src/geo/kmeans_optimized.py (kpp_initialization_graph :14, assign_points_to_medoids :77,
 compute_quantization_error :109, fit_kmedoids_optimized :141, fit_kmedoids_with_connectivity_check :186).
 
-The shortest-path solves run in csrc/sssp.hip on a graph that stays resident in HBM.  The k-means++
-draw itself is numpy's legacy RandomState (float32 D^2 weights, float32 pairwise sum, fp64 cdf,
-searchsorted) executed on the host on the downloaded d_min vector, exactly as in
-kmeans_optimized.py:47-69 -- it IS the reference's sampling semantics and costs N*4 bytes of
-device->host traffic per centre.
+The graph stays resident in HBM.  The whole k-means++ chain runs on the GPU (csrc/kpp.hip): pruned frontier
+solves from each new centre, the running (min, first-argmin) update, and numpy's legacy RandomState.choice draw
+restated bit for bit (float32 D^2 weights, float32 pairwise add.reduce, fp64 cdf, searchsorted); the host only
+supplies the uniform deviates of the same RandomState stream and steps in for the rare draws the device declines
+(u within rounding reach of a cdf step, degenerate weights).  GEO_KPP_HOST_DRAW=1 selects the reference's own
+structure instead -- one device solve + one numpy draw on the downloaded d_min per centre (kmeans_optimized.py:47-69);
+the tests compare both.
 """
 import os
 from typing import List, Optional, Tuple
@@ -123,9 +125,16 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     N, dev = G.n, G.indptr.device
     rng = np.random.RandomState(seed)
     first = int(rng.randint(0, N))
+    # One RandomState, advanced in lock-step with the committed draws: u[t] is the deviate the reference's
+    # rng.choice(N, p=probs) consumes for centre t+1.  The deviates are pre-drawn from `base_state` (the stream position
+    # before draw `base_t`); a uniform fallback (degenerate weights) consumes the stream differently, so it is replayed
+    # from base_state and the remaining deviates are drawn afresh from the position it leaves behind.
+    base_state, base_t = rng.get_state(), 0
     u = rng.random_sample(max(K - 1, 0)) if K > 1 else np.zeros(0)
     u = np.ascontiguousarray(u, dtype=np.float64)
-    chain = _Chain(G)
+    chain = _Chain(G)           # chain.ws and `ws` below alias the same cached workspace buffer: geo_kpp_chain
+    #                             re-initialises all of its workspace state on every call, and chain.absorb (which
+    #                             overwrites it) only runs between two geo_kpp_chain calls, never during one
     centers_d = torch.zeros(max(K, 1), dtype=torch.int32, device=dev)
     centers_d[0] = first
     is_center = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -174,19 +183,19 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
             break
         nxt = _draw_with_u(N, chain.dmin.cpu().numpy(), centers_h, float(u[t]))
         if nxt is None:                                  # degenerate weights: the reference's uniform fallback
-            rng2 = np.random.RandomState(seed)
-            rng2.randint(0, N)
-            if t > 0:
-                rng2.random_sample(t)
+            rng.set_state(base_state)
+            if t > base_t:
+                rng.random_sample(t - base_t)            # the p-weighted draws committed since base_t
             taken = set(centers_h)
             rest = [i for i in range(N) if i not in taken]
             if not rest:
                 print(f"Warning: Could not find {K} valid centers, stopping at {len(centers_h)}")
                 n_valid = t + 1
                 break
-            nxt = int(rng2.choice(rest))
+            nxt = int(rng.choice(rest))                  # kmeans_optimized.py:66
+            base_state, base_t = rng.get_state(), t + 1
             if K - 2 - t > 0:
-                u[t + 1:] = rng2.random_sample(K - 2 - t)
+                u[t + 1:] = rng.random_sample(K - 2 - t)
         centers_d[t + 1] = nxt
         is_center[nxt] = 1
         it = t + 1

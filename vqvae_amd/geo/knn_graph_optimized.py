@@ -77,15 +77,23 @@ def _drop_self(dist: torch.Tensor, idx: torch.Tensor):
     return dist_k.contiguous(), idx_k.contiguous()
 
 
-def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual", group=None):
-    """Resident latents -> (DeviceCSR, distances f64 [N,k'], indices int32 [N,k']); k' = min(k, N-1) >= 1.
-    With an initialised process group the query rows are sharded over the ranks (parallel.sharded_knn)."""
+def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual", group=None,
+                     need_dist: bool = True):
+    """Resident latents -> (DeviceCSR, distances f64 [N,k'] | None, indices int32 [N,k']); k' = min(k, N-1) >= 1.
+    With an initialised process group the query rows are sharded over the ranks (parallel.sharded_knn); a
+    connectivity graph with need_dist=False then never gathers the fp64 distances (returned as None)."""
     from ..parallel import sharded_knn
     if sym not in _SYM_MODE:
         raise ValueError(f"Invalid symmetry mode: {sym}")
     N = z.shape[0]
     k_eff = max(0, min(k, N - 1))
-    idx, d2 = sharded_knn(z, min(k_eff + 1, N), knn_search_device, group)
+    idx, d2 = sharded_knn(z, min(k_eff + 1, N), knn_search_device, group,
+                          gather_d2=need_dist or mode == "distance")
+    if callable(d2):                  # multi-rank connectivity graph: distances only if a self match is displaced
+        me = torch.arange(N, device=idx.device, dtype=idx.dtype)
+        if bool((idx[:, 0] == me).all()):          # same gathered idx on every rank -> same decision on every rank
+            return symmetrize_device(idx[:, 1:].contiguous(), None, sym), None, idx[:, 1:].contiguous()
+        d2 = d2()
     dist, idx = _drop_self(torch.sqrt(d2), idx)
     weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
     return symmetrize_device(idx, weights, sym), dist, idx

@@ -4,7 +4,8 @@ CPU tests).  The reference has no distributed code; this layer is new.
 
 What shards and what is exchanged
   kNN             query rows are block-sharded, the corpus is replicated (all-gather of the latent row
-                  shards, N*d*4 bytes) -> all-gather of the neighbour lists (N*(k+1)*12 bytes).
+                  shards, N*d*4 bytes) -> all-gather of the neighbour lists (N*(k+1)*4 bytes; the fp64 distances,
+                  another N*(k+1)*8 bytes, only for mode="distance" graphs or when duplicates displace a self match).
   edge lengths    sharded by CHUNK index (a chunk of `batch_size` consecutive edges is one BatchNorm batch,
                   so train-mode statistics do not change) -> all-gather of the lengths (E*4 bytes).
   K-source solve  sources are block-sharded -> every rank reduces its sources to (dmin, argmin) per node ->
@@ -56,9 +57,11 @@ def gather_latents(z_shard: torch.Tensor, n_total: int, group=None) -> torch.Ten
     return all_gather_rows(z_shard.contiguous(), counts, group)
 
 
-def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=None):
+def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=None, gather_d2: bool = True):
     """search_fn(z, n_neighbors, row0, row1) -> (idx [rows, n_neighbors], d2 [rows, n_neighbors]).
-    Returns the full (idx, d2) on every rank."""
+    Returns the full idx on every rank and the full d2 when gather_d2 (the fp64 distances are 2/3 of the bytes and a
+    connectivity graph never reads them); otherwise a callable that gathers d2 on demand (collective: every rank
+    must call it or none)."""
     rank, world = world_info(group)
     n = z.shape[0]
     r0, r1 = block_range(n, rank, world)
@@ -66,7 +69,10 @@ def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=No
     if world == 1:
         return idx, d2
     counts = [block_range(n, r, world)[1] - block_range(n, r, world)[0] for r in range(world)]
-    return all_gather_rows(idx, counts, group), all_gather_rows(d2, counts, group)
+    idx_all = all_gather_rows(idx, counts, group)
+    if gather_d2:
+        return idx_all, all_gather_rows(d2, counts, group)
+    return idx_all, (lambda: all_gather_rows(d2, counts, group))
 
 
 def chunk_range(n_edges: int, batch_size: int, rank: int, world: int) -> Tuple[int, int]:

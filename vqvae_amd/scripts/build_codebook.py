@@ -25,7 +25,7 @@ from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
                                        upper_edges_device)
 from ..geo.riemannian_metric import edge_lengths_graph_device, edge_lengths_riemannian
-from ..parallel import sharded_edge_lengths
+from ..parallel import sharded_edge_lengths, world_info
 from ..spatial_decoder import DecoderExport, hip_kernels_cover, load_decoder_from_checkpoint
 
 
@@ -45,11 +45,13 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
         return time.perf_counter()
 
     t0 = time.perf_counter()
-    G, _, _ = knn_graph_device(z_flat, k, mode="connectivity", sym=sym, group=group)
+    G, _, _ = knn_graph_device(z_flat, k, mode="connectivity", sym=sym, group=group, need_dist=False)
     src, dst, entry_edge = upper_edges_device(G)
     t0 = tick("knn", t0)
 
     print(f"Re-weighting {src.numel()} edges using Riemannian metric...")
+    world = world_info(group)[1]
+    sharded = {"knn": world > 1, "jvp": world > 1 and hip_kernels_cover(decoder)}   # what the ranks really split
     if hip_kernels_cover(decoder):
         export = DecoderExport(decoder, dev)
         # whole chunks of `batch_size` edges per rank: every BatchNorm batch stays intact
@@ -82,7 +84,8 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
     assign_flat[mask_h] = assign_lcc
     z_medoid = z_lcc[torch.from_numpy(medoids).to(dev)].cpu()
     return {"W_lcc": W_lcc, "mask_lcc": mask_h, "medoids": medoids, "assign_flat": assign_flat, "qe": qe,
-            "z_medoid": z_medoid, "n_edges": int(src.numel()), "edge_lengths": lengths, "edges": (src, dst)}
+            "z_medoid": z_medoid, "n_edges": int(src.numel()), "edge_lengths": lengths, "edges": (src, dst),
+            "sharded": sharded}
 
 
 def main(args):
