@@ -14,7 +14,8 @@
  *   - no allocation crosses the ABI: the caller owns inputs, outputs and the workspace `ws`
  *     (size from the matching *_workspace_bytes query, any 256-byte aligned device buffer);
  *   - return value: 0 = ok, negative = error (GEO_E_*); geo_last_error() gives the text;
- *   - thread-compatible, not thread-safe (one call at a time per process).
+ *   - thread-compatible, not thread-safe: ONE call at a time per process.  geo_last_error's buffer, the options of
+ *     geo_set_option, the sweep profile of geo_sssp_last_profile and its HIP events are process-global.
  */
 #ifndef GEO_HIP_H
 #define GEO_HIP_H
@@ -34,6 +35,11 @@ extern "C" {
 
 int geo_version(void);
 const char *geo_last_error(void);
+
+/* Experiment switches ("sssp_group", "knn_filter", "kpp_profile", ...: the table in DESIGN.md).  They are seeded from
+ * the GEO_* environment variables ONCE, when the library is first called; afterwards only this call changes them.
+ * Process-wide and not synchronised (like the rest of the library: one call at a time).  GEO_E_ARG: unknown name. */
+int geo_set_option(const char *name, int32_t value);
 
 /* ------------------------------------------------------------------------------------------
  * Shortest paths.  Replaces scipy.sparse.csgraph.dijkstra as called from
@@ -82,17 +88,21 @@ int geo_sssp_single_update(const int32_t *indptr, const int32_t *indices, const 
  * the caller took from the same RandomState stream.  centers i32 [n_centers_total] (centers[it0] set by
  * the caller), is_center u8 [n] (set for centers[0..it0]), dmin f32 [n] / argmin i32 [n] carried state.
  * sweeps_per_solve relaxation sweeps are enqueued per solve (they exit early once converged); 0 (needs
- * assume_finite) runs the chain as one step kernel launched until done: no budget, reason 1 only past 4094 sweeps.
+ * assume_finite) runs the chain as one step kernel launched until done: no budget, reason 1 only past 4094 sweeps;
+ * -1 (needs assume_finite and n <= geo_kpp_resident_max_nodes()) runs iterations [it0, it1) inside ONE resident
+ * workgroup in a single launch (solve in an LDS hash table, incremental float32 reduction tree, draw): the mode for
+ * small cells; a centre whose cell outgrows the table is run by the step kernel inside the call.
  * assume_finite != 0 promises that d_min has no inf entry left (status_out[2] of an earlier call): the
  * per-iteration maximum pass is skipped.
  * status_out [host, 4 ints]: {abort_iter or -1, reason, inf entries of d_min at the last maximum pass,
  * most sweeps any solve of this call needed (step kernel: launches that did work)}:
  * reason 1 = solve not converged (nothing of that iteration is applied), 2 = u too close to a cdf boundary,
  * 3 = degenerate weights (for 2 and 3 the solve of that iteration IS applied, the draw is not).  The caller
- * repeats that step another way and resumes.
+ * repeats that step another way and resumes.  Resident mode: status_out[3] = centres handed to the step kernel.
  * One synchronisation at the end.
  * ------------------------------------------------------------------------------------------ */
 size_t geo_kpp_workspace_bytes(int32_t n);
+int32_t geo_kpp_resident_max_nodes(void);
 int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
                   int32_t *centers, uint8_t *is_center, float *dmin, int32_t *argmin, const double *u_host,
                   int32_t it0, int32_t it1, int32_t n_centers_total, int32_t sweeps_per_solve,

@@ -131,6 +131,79 @@ def edge_lengths(sd: Mapping, norm_type: str, output_image_size: int, z_start, z
         _DEVICE = prev
 
 
+def _dense_maps(sd: Mapping, output_image_size: int, dtype):
+    """The three transposed convolutions on the decoder's 1x1 latent image as dense matrices (an exact copy of the
+    weights: each row is the layer applied to a one-hot input, bias removed).  Shapes (c_in*h*w, c_out*2h*2w)."""
+    pad_last = {28: 3, 32: 1}[int(output_image_size)]
+    maps, hw = [], 1
+    for conv, pad in ((0, 1), (3, 1), (6, pad_last)):
+        w = _t(sd, f"deconv_layers.{conv}.weight", dtype)
+        cin = w.shape[0]
+        eye = torch.eye(cin * hw * hw, dtype=dtype, device=w.device).view(cin * hw * hw, cin, hw, hw)
+        out = F.conv_transpose2d(eye, w, None, stride=2, padding=pad)
+        maps.append((out.reshape(cin * hw * hw, -1), out.shape[1], out.shape[2]))
+        hw = out.shape[2]
+    return maps
+
+
+def edge_lengths_dense(sd: Mapping, output_image_size: int, z_start, z_end, batch_size: int = 512,
+                       dtype=torch.float64, device: str = "cpu") -> torch.Tensor:
+    """The same closed form as edge_lengths(norm_type="batch", training=True) with every layer written as a dense
+    matrix product over whole stacks of chunks (the decoder sees a 1x1 latent image, so each transposed convolution
+    is a small matrix): identical in exact arithmetic, fp64 rounding differs at 1e-16.  This is what makes the fp64
+    check of EVERY BatchNorm chunk of a full-size run affordable (tests tie it to edge_lengths on sample chunks)."""
+    global _DEVICE
+    prev, _DEVICE = _DEVICE, device
+    try:
+        with torch.no_grad():
+            zs = torch.as_tensor(z_start).to(device, dtype)
+            ze = torch.as_tensor(z_end).to(device, dtype)
+            E = zs.shape[0]
+            w_in = _t(sd, "conv_in.weight", dtype).view(-1, zs.shape[1])
+            b_in = _t(sd, "conv_in.bias", dtype)
+            maps = _dense_maps(sd, output_image_size, dtype)
+            out = torch.empty(E, dtype=dtype, device=device)
+            full = (E // batch_size) * batch_size
+            stack = 64 * batch_size                                  # chunks processed together
+
+            def run(zs_, ze_, nb, bs):                               # nb chunks of bs edges
+                delta = ze_ - zs_
+                res = 0.0
+                for z0 in (zs_, ze_):
+                    x = z0 @ w_in.t() + b_in                         # (nb*bs, c0)
+                    t = delta @ w_in.t()
+                    for li, (norm, bias) in enumerate(((1, 0), (4, 3), (None, 6))):
+                        M, cout, hw = maps[li]
+                        b = _t(sd, f"deconv_layers.{bias}.bias", dtype)
+                        x = (x @ M).view(nb, bs, cout, hw * hw) + b.view(1, 1, -1, 1)
+                        t = (t @ M).view(nb, bs, cout, hw * hw)
+                        if norm is None:
+                            break
+                        gamma = _t(sd, f"deconv_layers.{norm}.weight", dtype).view(1, 1, -1, 1)
+                        beta = _t(sd, f"deconv_layers.{norm}.bias", dtype).view(1, 1, -1, 1)
+                        mu = x.mean(dim=(1, 3), keepdim=True)
+                        var = ((x - mu) ** 2).mean(dim=(1, 3), keepdim=True)
+                        inv = 1.0 / torch.sqrt(var + BN_EPS)
+                        xhat = (x - mu) * inv
+                        that = inv * (t - t.mean(dim=(1, 3), keepdim=True) - xhat * (xhat * t).mean(dim=(1, 3), keepdim=True))
+                        x = xhat * gamma + beta
+                        t = (that * gamma) * (x > 0).to(dtype)
+                        x = torch.relu(x)
+                        x, t = x.reshape(nb * bs, -1), t.reshape(nb * bs, -1)
+                    sg = torch.sigmoid(x)
+                    res = res + 0.5 * torch.linalg.vector_norm((t * sg * (1.0 - sg)).reshape(nb * bs, -1), dim=1)
+                return res
+
+            for lo in range(0, full, stack):
+                hi = min(lo + stack, full)
+                out[lo:hi] = run(zs[lo:hi], ze[lo:hi], (hi - lo) // batch_size, batch_size)
+            if full < E:
+                out[full:] = run(zs[full:], ze[full:], 1, E - full)
+            return out.to("cpu", torch.float32)
+    finally:
+        _DEVICE = prev
+
+
 def make_decoder_state(seed: int, latent_dim: int, out_channels: int, channels=(256, 128, 64),
                        norm_type: str = "batch") -> dict:
     """Seeded synthetic SpatialDecoder weights (golden fixture G3): numpy RandomState, so the same

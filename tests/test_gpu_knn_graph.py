@@ -123,17 +123,21 @@ def _oracle_rows(z, n_neighbors, form, r0, r1):
 
 
 @pytest.mark.parametrize("d,filt", [(16, "1"), (8, "1"), (24, "1"), (64, "1"), (16, "0")])
-def test_large_corpus_filter_path_vs_oracle(d, filt, monkeypatch):
+def test_large_corpus_filter_path_vs_oracle(d, filt):
     """Above 40 000 rows the search runs behind the float32 matrix-core filter (subset thresholds, MFMA scan, exact
     fp64 refinement of the kept candidates); lists and fp64 keys must equal the oracle's, as without the filter --
     expansion form (d > 15), direct form (d <= 15) and a padded dimension (24 -> 32)."""
     import torch
     from vqvae_amd._device import device
     from vqvae_amd.geo.knn_graph_optimized import knn_search_device
-    monkeypatch.setenv("GEO_KNN_FILTER", filt)
+    from vqvae_amd import _lib
     n, kq = 45000, 21
     z = latents(n, d, 21)
-    idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    _lib.check(_lib.load().geo_set_option(b"knn_filter", int(filt)), "geo_set_option")
+    try:
+        idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    finally:
+        _lib.load().geo_set_option(b"knn_filter", 1)
     idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
     for r0, r1 in ((0, 48), (22000, 22048), (n - 48, n)):
         io, do = _oracle_rows(z, kq, 1 if d > 15 else 0, r0, r1)

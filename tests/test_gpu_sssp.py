@@ -92,7 +92,7 @@ def test_many_sources_vs_oracle(n_sources):
 
 
 @pytest.mark.parametrize("group", ["0", "1", "2"])
-def test_long_geodesics_16_source_batches(group, monkeypatch):
+def test_long_geodesics_16_source_batches(group, request):
     """Manifold-like latents (noisy swiss roll, ~100-hop geodesics) at a size that takes the 16-source chunk
     sweep, without / with automatic / with forced regrouping of the sources along landmark distances: distances,
     predecessors, column minimum and first-row argmin (duplicate sources force ties) against the oracle."""
@@ -101,7 +101,9 @@ def test_long_geodesics_16_source_batches(group, monkeypatch):
     from oracle import sssp as osp
     from vqvae_amd._device import DeviceCSR, device
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
-    monkeypatch.setenv("GEO_SSSP_GROUP", group)
+    from vqvae_amd import _lib
+    _lib.check(_lib.load().geo_set_option(b"sssp_group", int(group)), "geo_set_option")
+    request.addfinalizer(lambda: _lib.load().geo_set_option(b"sssp_group", 1))
     n = 14000
     W, _ = okn.build_knn_graph(swiss_roll_latents(n, 16, 3), k=10, mode="distance", sym="union")
     src = np.random.RandomState(5).choice(n, 70, replace=False)
@@ -237,3 +239,31 @@ def test_repeated_uniform_fallbacks_follow_the_reference_stream(golden):
             np.testing.assert_array_equal(med, g[f"case{i}/medoids"], err_msg=str((sizes, K, seed, host_draw)))
             np.testing.assert_array_equal(assign, g[f"case{i}/assign"])
             assert qe == float(g[f"case{i}/qe"])
+
+
+def test_resident_chain_equals_step_kernel_and_oracle():
+    """The resident single-workgroup chain (kpp_resident_kernel: LDS hash solve, incremental numpy sum, in-workgroup
+    draw) against the step kernel and the oracle; entering it at centre 1 makes the first cells overflow its table, which
+    exercises the hand-back (abort reason 4 -> that centre by the step kernel -> resume)."""
+    from oracle import kmedoids as ok
+    from oracle import knn as okn
+    from vqvae_amd.geo import kmeans_optimized as km
+    cases = [(okn.build_knn_graph(latents(20011, 16, 11), k=10, mode="distance", sym="union")[0], 96, 42),
+             (okn.build_knn_graph(latents(8200, 8, 5), k=6, mode="distance", sym="union")[0], 200, 7),     # ragged numpy chunk
+             (okn.build_knn_graph(swiss_roll_latents(6000, 16, 3), k=8, mode="distance", sym="union")[0], 64, 1)]
+    saved = dict(km._KNOBS)
+    try:
+        for W, K, seed in cases:
+            got = {}
+            for tag, knobs in (("step", {"resident": False}), ("resident", {"resident": True, "resident_from": 16}),
+                               ("resident_early", {"resident": True, "resident_from": 1})):
+                km._KNOBS.update(saved)
+                km._KNOBS.update(knobs)
+                got[tag] = km.fit_kmedoids_optimized(W, K=K, init="kpp", seed=seed)
+            mo, ao, qo = ok.fit_kmedoids_single_pass(W, K=K, seed=seed)
+            for tag, (med, assign, qe) in got.items():
+                np.testing.assert_array_equal(med, mo, err_msg=tag)
+                np.testing.assert_array_equal(assign, ao, err_msg=tag)
+                assert qe == qo, tag
+    finally:
+        km._KNOBS.update(saved)

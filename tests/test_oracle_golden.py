@@ -201,3 +201,20 @@ def test_c2_fixture_structure_and_first_draws(golden):
     rows = np.repeat(np.arange(n), np.diff(W.indptr))
     Wf = sparse.csr_matrix((syn.formula_weights(rows, W.indices), W.indices, W.indptr), shape=(n, n))
     assert ok.kpp_initialization_graph(Wf, 6, seed=seed) == g["medoids"][:6].tolist()
+
+
+def test_dense_closed_form_equals_layer_by_layer(golden):
+    """oracle.metric.edge_lengths_dense (every transposed convolution on the 1x1 latent image as a matrix, stacks of
+    chunks at once: the full-size fp64 checker) against the layer-by-layer closed form and the reference's lengths."""
+    for name, (d, cout, size, seed) in {"fm_batch": (16, 1, 28, 10), "cf_batch": (32, 3, 32, 13)}.items():
+        sd = om.make_decoder_state(seed, d, cout, norm_type="batch")
+        r = np.random.RandomState(100 + seed)
+        zs = r.randn(2048, d).astype(np.float32)
+        ze = (zs + 0.3 * r.randn(2048, d)).astype(np.float32)
+        for bs, E in ((512, 2048), (100, 2048), (512, 1300)):
+            a = om.edge_lengths(sd, "batch", size, zs[:E], ze[:E], batch_size=bs, training=True, dtype=torch.float64).numpy()
+            b = om.edge_lengths_dense(sd, size, zs[:E], ze[:E], batch_size=bs).numpy()
+            np.testing.assert_allclose(a, b, rtol=2e-7)
+        ref = golden("metric")[f"{name}/train1/bs512"]
+        rel = np.abs(om.edge_lengths_dense(sd, size, zs, ze, batch_size=512).numpy() - ref) / ref
+        assert np.quantile(rel, 0.99) < 2e-6

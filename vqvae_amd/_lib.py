@@ -25,11 +25,13 @@ class DecoderDesc(ctypes.Structure):
 _SIGNATURES = {
     "geo_version": (ctypes.c_int, []),
     "geo_last_error": (ctypes.c_char_p, []),
+    "geo_set_option": (ctypes.c_int, [ctypes.c_char_p, i32]),
     "geo_sssp_workspace_bytes": (sz, [i32, i64, i32]),
     "geo_sssp_multi": (ctypes.c_int, [c_p, c_p, c_p, i32, i64, c_p, i32, c_p, c_p, c_p, c_p, c_p, sz, c_p, c_p]),
     "geo_sssp_last_profile": (ctypes.c_int, [c_p, c_p]),
     "geo_sssp_single_update": (ctypes.c_int, [c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i32, c_p, sz, c_p, c_p]),
     "geo_kpp_workspace_bytes": (sz, [i32]),
+    "geo_kpp_resident_max_nodes": (i32, []),
     "geo_kpp_chain": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p, sz, c_p, c_p]),
     "geo_knn_workspace_bytes": (sz, [i64, i32]),
     "geo_knn_topk": (ctypes.c_int, [c_p, i64, i32, i32, i32, i64, i64, c_p, c_p, c_p, sz, c_p]),

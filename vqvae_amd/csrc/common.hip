@@ -1,9 +1,43 @@
 // common.hip -- error reporting and the device prefix sum used by the graph kernels.
 #include "geo_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace geo {
+
+namespace {
+struct OptionName { const char *name, *env; int Options::*field; };
+const OptionName kOptionNames[] = {
+    {"sssp_sb", "GEO_SSSP_SB", &Options::sssp_sb},
+    {"sssp_act", "GEO_SSSP_ACT", &Options::sssp_act},
+    {"sssp_sparse_div", "GEO_SSSP_SPARSE_DIV", &Options::sssp_sparse_div},
+    {"sssp_map_div", "GEO_SSSP_MAP_DIV", &Options::sssp_map_div},
+    {"sssp_group", "GEO_SSSP_GROUP", &Options::sssp_group},
+    {"sssp_grouped_cap", "GEO_SSSP_GROUPED_CAP", &Options::sssp_grouped_cap},
+    {"sssp_trace", "GEO_SSSP_TRACE", &Options::sssp_trace},
+    {"knn_filter", "GEO_KNN_FILTER", &Options::knn_filter},
+    {"kpp_grid", "GEO_KPP_GRID", &Options::kpp_grid},
+    {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},
+    {"jvp_mid", "GEO_JVP_MID", &Options::jvp_mid},
+    {"jvp_back_valu", "GEO_JVP_BACK_VALU", &Options::jvp_back_valu},
+};
+Options from_environment() {
+    Options o;
+    for (const OptionName &e : kOptionNames) {
+        const char *v = getenv(e.env);
+        if (!v) continue;
+        if (e.field == &Options::jvp_mid) o.jvp_mid = v[0] == 'f' ? 1 : (v[0] == 'c' ? 2 : atoi(v));
+        else o.*(e.field) = atoi(v);
+    }
+    return o;
+}
+}  // namespace
+
+Options &options() {
+    static Options o = from_environment();       // the environment is read once, at the first call into the library
+    return o;
+}
 
 static char g_err[512] = "";
 
@@ -127,3 +161,14 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, void *tmp, si
 
 extern "C" int geo_version(void) { return 100; }
 extern "C" const char *geo_last_error(void) { return geo::g_err; }
+
+extern "C" int geo_set_option(const char *name, int32_t value) {
+    if (name)
+        for (const geo::OptionName &e : geo::kOptionNames)
+            if (strcmp(name, e.name) == 0) {
+                geo::options().*(e.field) = value;
+                return GEO_OK;
+            }
+    geo::set_error("geo_set_option: unknown option '%s'", name ? name : "(null)");
+    return GEO_E_ARG;
+}

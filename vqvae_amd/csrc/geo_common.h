@@ -31,6 +31,15 @@ void set_error(const char *fmt, ...);
 
 #define GEO_LAUNCH_CHECK() GEO_HIP_CHECK(hipGetLastError())
 
+// Experiment switches (DESIGN.md "Experiment switches").  Seeded ONCE from the environment when the library is
+// loaded; afterwards only geo_set_option() changes them.  -1 = automatic / default behaviour.
+struct Options {
+    int sssp_sb = -1, sssp_act = 1, sssp_sparse_div = -1, sssp_map_div = -1, sssp_group = 1, sssp_grouped_cap = 256,
+        sssp_trace = 0, knn_filter = 1, kpp_grid = 256, kpp_profile = 0, jvp_mid = 0 /* 1 = f32 MFMA, 2 = per-chunk */,
+        jvp_back_valu = 0;
+};
+Options &options();
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace.

@@ -1018,10 +1018,10 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     pack_back_kernel<<<geo::grid_for(16 * s.co * s.c2, 256), 256, 0, stream>>>(dc->w3, s.c2, s.co, W3p);
     GEO_LAUNCH_CHECK();
     // ConvT2 on the matrix cores: bf16 x 3 split by default, exact-f32 MFMA with GEO_JVP_MID=f32
-    const char *mid_env = getenv("GEO_JVP_MID");
-    const bool mid_split = !(mid_env && mid_env[0] == 'f') && s.c1 % 16 == 0;
+    const int mid_opt = geo::options().jvp_mid;
+    const bool mid_split = mid_opt != 1 && s.c1 % 16 == 0;
     const int back_nt = (s.p_out + 31) / 32;
-    const bool back_mfma = mid_split && s.c2 == 64 && (back_nt == 1 || back_nt == 6) && !getenv("GEO_JVP_BACK_VALU");
+    const bool back_mfma = mid_split && s.c2 == 64 && (back_nt == 1 || back_nt == 6) && !geo::options().jvp_back_valu;
     if (back_mfma) {
         pack_back_bf16_kernel<<<geo::grid_for((int64_t)16 * s.c2 * back_nt * 32, 256), 256, 0, stream>>>(
             dc->w3, s.c2, s.co, s.s_out, s.pad3, back_nt * 32, W3b);
@@ -1036,7 +1036,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     if (dc->norm == 2) {
         // the GroupNorm path exists for the 32-group layouts of the matrix-core kernels (reference default decoder)
         GEO_REQUIRE(dc->groups1 == 32 && dc->groups2 == 32 && s.c2 == 64 && back_mfma && mid_split && s.n_chunks == 8 &&
-                        s.opix_per_chunk == 2 && !(mid_env && mid_env[0] == 'c'),
+                        s.opix_per_chunk == 2 && mid_opt != 2,
                     "geo_decoder_jvp: GroupNorm needs 32 groups per layer and dec_channels[2] == 64 (got %d/%d groups, c2=%d)",
                     dc->groups1, dc->groups2, s.c2);
     }
@@ -1087,7 +1087,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                                                     s.opix_per_chunk, s.c2, B3, dc->b2, pre2, tpre2, part2,        \
                                                     batch_stats ? 1 : 0, slot_valid)
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
-                             !(mid_env && mid_env[0] == 'c');
+                             mid_opt != 2;
         if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \

@@ -406,9 +406,7 @@ int launch_knn(bool expansion, const float *zp32, const double *zq64, const doub
 
 
 bool filter_applies(int64_t n, int dp) {
-    if (const char *e = getenv("GEO_KNN_FILTER")) {
-        if (atoi(e) == 0) return false;
-    }
+    if (geo::options().knn_filter == 0) return false;
     // worth it from ~40 000 rows at 16 dimensions; the exact scan costs in proportion to the dimension
     const int64_t n_min = 640000 / dp > 16384 ? 640000 / dp : 16384;
     return n >= n_min && (dp == 8 || dp == 16 || dp == 32 || dp == 64);

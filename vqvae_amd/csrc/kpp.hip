@@ -576,6 +576,509 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
     }
 }
 
+// ---- the chain as ONE resident workgroup ----------------------------------------------------------------------
+// Once the cells are small (a few thousand nodes) a centre costs microseconds of work but ~6 dependent kernel launches
+// of ~9 us each.  Here ONE 1024-thread workgroup stays resident and runs centre after centre, with workgroup barriers
+// and LDS where the step kernel has kernel boundaries and agent-scope round trips:
+//   solve   the pruned frontier solve with the tentative fp64 distances in an LDS hash table (open addressing,
+//           ds_cmpst on the key, ds_min_u64 on the bit pattern of the distance): a candidate that cannot improve its
+//           node (cand > d_min + tau) is never stored, so the table only holds the new centre's cell; frontier queues of
+//           table slots in LDS, one "queued" bit per entry.  Nothing global is written before the solve has converged;
+//   apply   d_min / argmin of the improved nodes (the only global stores), their numpy leaves marked dirty;
+//   sum     numpy's float32 add.reduce incrementally: the tree of leaf sums lives in LDS, only dirty leaves are
+//           re-read (the tree's shape depends on N alone, so this is numpy's result bit for bit), then the levels;
+//   draw    p = w / total, per-leaf fp64 sums, scan over the leaves, pick inside one leaf with the same margin rule as
+//           kpp_draw_body; commit and open the next solve.
+// The same arithmetic as the step kernel (fp64 candidate = du + w, float32 w = d_min^2 without contraction, correctly
+// rounded division), so centres, assignments and d_min are identical.  A cell that does not fit the table ends the
+// kernel with abort reason 4 and nothing of that iteration applied; the caller runs that one centre with the step kernel.
+constexpr int PG_THREADS = 1024, PG_HASH = 8192, PG_HASH_MAX = 4096, PG_QCAP = 4096, PG_TOUCH = 5120, PG_MAX_LEAVES = 768,
+              PG_TILE = 256, PG_SEGCAP = 2048;
+constexpr double KPP_APPROX_MARGIN = 1.25e-7;          // > 2 * 2^-24 + N * 2^-52 for every N the resident chain accepts
+constexpr unsigned PG_EMPTY = 0xffffffffu, PG_FLAG = 0x80000000u, PG_MASK = 0x7fffffffu;
+constexpr int32_t PG_MAX_NODES = 90000;
+
+struct ResidentPlan {                      // numpy's reduction tree (SumPlan) + what the resident kernel adds
+    const int32_t *leaf_start, *leaf_len, *node_l, *node_r, *level_off, *chunk_root;
+    const uint16_t *tail_leaf;             // leaf of node v >= tail_start: tail_leaf[v - tail_start]
+    int n_leaves, n_nodes, n_levels, n_chunks;
+    int32_t tail_start, tail_first_leaf;   // nodes below tail_start sit in full 8192-chunks: 64 leaves of 128
+};
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(PG_THREADS) void kpp_resident_kernel(KppCtl *ctl, const int32_t *__restrict__ indptr,
+                                                                  const int32_t *__restrict__ indices,
+                                                                  const float *__restrict__ weights, int32_t n,
+                                                                  float *dmin, int32_t *argmin, int32_t *centers,
+                                                                  uint8_t *is_center, const double *__restrict__ u_dev,
+                                                                  double tol, ResidentPlan pl, int32_t it0, int32_t it1,
+                                                                  int32_t n_centers_total, int32_t *progress,
+                                                                  unsigned long long *prof) {
+    // prof (diagnostic runs of the CALLER only, normally null): cycles per phase summed over the centres,
+    // [0] solve [1] apply [2] leaf sums [3] locate [4] exact draws (tree + full pass + locate) [5] exact draws taken
+    // [6] sweeps [7] frontier nodes
+    unsigned long long pt = 0, pacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] init [9] marks [10] fill [11] pass-rest [12] pass loads [13] pass relax
+#define GEO_STAMP(k)                                                        \
+    if (prof && threadIdx.x == 0) {                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+        pacc[k] += now_ - pt;                                               \
+        pt = now_;                                                          \
+    }
+    __shared__ unsigned long long h_dist[PG_HASH];
+    __shared__ unsigned h_key[PG_HASH];
+    __shared__ unsigned short queue[2][PG_QCAP], touched[PG_TOUCH];
+    __shared__ double n_du[PG_TILE];
+    __shared__ int32_t n_e0[PG_TILE], n_e1[PG_TILE], s_level_off[32], s_chunk_root[64];
+    // the segment list of a frontier tile (solve) and the exact per-leaf sums of p (an exact draw) never live together
+    __shared__ __attribute__((aligned(8))) unsigned char s_scratch[PG_SEGCAP * 4 > (PG_MAX_LEAVES + 1) * 8 ? PG_SEGCAP * 4 : (PG_MAX_LEAVES + 1) * 8];
+    unsigned *segs = reinterpret_cast<unsigned *>(s_scratch);
+    double *leaf_q = reinterpret_cast<double *>(s_scratch);
+    __shared__ double leaf_a[PG_MAX_LEAVES + 1], leaf_e[PG_MAX_LEAVES + 1];
+    __shared__ float tree[2 * PG_MAX_LEAVES];
+    __shared__ unsigned short t_l[PG_MAX_LEAVES], t_r[PG_MAX_LEAVES], dirty_list[PG_MAX_LEAVES];
+    __shared__ unsigned char dirty[PG_MAX_LEAVES];
+    __shared__ double wave_tot[PG_THREADS / 64];
+    __shared__ float s_red[PG_THREADS / 64];
+    __shared__ int32_t s_qcnt[2], s_entries, s_overflow, s_ndirty, s_nseg, s_leaf, s_pick[2];
+    __shared__ float s_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_leaves = pl.n_leaves, n_nodes = pl.n_nodes;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // ---- prologue: pruning margin (max of the finite d_min), tree plan into LDS, every leaf dirty, empty table ----
+    {
+        float m = 0.0f;
+        for (int32_t i = tid; i < n; i += PG_THREADS) m = fmaxf(m, dmin[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) s_red[wave] = m;
+        for (int j = tid; j < n_nodes; j += PG_THREADS) { t_l[j] = (unsigned short)pl.node_l[j]; t_r[j] = (unsigned short)pl.node_r[j]; }
+        for (int j = tid; j < n_leaves; j += PG_THREADS) dirty[j] = 1;
+        if (tid <= pl.n_levels && tid < 32) s_level_off[tid] = pl.level_off[tid];
+        if (tid < pl.n_chunks && tid < 64) s_chunk_root[tid] = pl.chunk_root[tid];
+        for (int sl = tid; sl < PG_HASH; sl += PG_THREADS) { h_key[sl] = PG_EMPTY; h_dist[sl] = 0x7ff0000000000000ull; }
+        if (tid == 0) s_entries = 0;
+    }
+    __syncthreads();
+    float maxf = 0.0f;
+#pragma unroll
+    for (int w = 0; w < PG_THREADS / 64; ++w) maxf = fmaxf(maxf, s_red[w]);
+    const double tau = maxf > 0.f ? 1e-6 * (double)maxf : 0.0;
+    const int sub = tid & 31, half = (tid >> 5) & 1;           // 32 lanes per row segment, two segments per wave
+
+    // Four candidates per lane (one per row segment the half wave holds), every lane of the wave takes part.  A candidate
+    // is stored only if it can still improve its node.  The four table look-ups, inserts, 64-bit minima and queue marks
+    // are issued side by side (one dependent LDS chain for all four); table / queue tails advance once per wave.
+    auto relax4 = [&](const bool (&pred)[4], const int32_t (&v)[4], const double (&cand)[4], const float (&dv)[4], int nxt) {
+        unsigned h[4], k[4];
+        bool want[4], found[4], isnew[4], slow[4], qf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            want[q] = pred[q] && (cand[q] <= (double)dv[q] + tau);     // else: cannot improve v, never stored
+            h[q] = ((unsigned)v[q] * 2654435761u) >> 19;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = want[q] ? h_key[h[q]] : 0u;
+        unsigned old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            found[q] = want[q] && k[q] != PG_EMPTY && (k[q] & PG_MASK) == (unsigned)v[q];
+            old[q] = (want[q] && k[q] == PG_EMPTY) ? atomicCAS(&h_key[h[q]], PG_EMPTY, (unsigned)v[q]) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            isnew[q] = want[q] && k[q] == PG_EMPTY && old[q] == PG_EMPTY;
+            if (want[q] && k[q] == PG_EMPTY && old[q] != PG_EMPTY && (old[q] & PG_MASK) == (unsigned)v[q]) found[q] = true;
+            found[q] = found[q] || isnew[q];
+            slow[q] = want[q] && !found[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                  // collisions (rare while the table is sparse)
+            if (slow[q]) {
+                for (int probe = 0; probe < 192; ++probe) {            // bounded: a long chain means the table is too full
+                    h[q] = (h[q] + 1) & (PG_HASH - 1);
+                    const unsigned kk = h_key[h[q]];
+                    if (kk != PG_EMPTY && (kk & PG_MASK) == (unsigned)v[q]) { found[q] = true; break; }
+                    if (kk == PG_EMPTY) {
+                        const unsigned o2 = atomicCAS(&h_key[h[q]], PG_EMPTY, (unsigned)v[q]);
+                        if (o2 == PG_EMPTY) { found[q] = isnew[q] = true; break; }
+                        if ((o2 & PG_MASK) == (unsigned)v[q]) { found[q] = true; break; }
+                    }
+                }
+                if (!found[q]) s_overflow = 1;
+            }
+        }
+        unsigned long long od[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            od[q] = found[q] ? atomicMin(&h_dist[h[q]], (unsigned long long)__double_as_longlong(cand[q])) : 0ull;
+        unsigned k0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool better = found[q] && (unsigned long long)__double_as_longlong(cand[q]) < od[q];
+            k0[q] = better ? atomicOr(&h_key[h[q]], PG_FLAG) : PG_FLAG;
+        }
+        unsigned long long mn[4], mq[4];
+        int cn = 0, cq = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            qf[q] = !(k0[q] & PG_FLAG);
+            mn[q] = __ballot(isnew[q]);
+            mq[q] = __ballot(qf[q]);
+            cn += __popcll(mn[q]);
+            cq += __popcll(mq[q]);
+        }
+        if (cn) {                                                      // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_entries, cn);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (isnew[q]) {
+                    const int at = base + __popcll(mn[q] & lane_lt);
+                    if (at < PG_TOUCH) touched[at] = (unsigned short)h[q]; else s_overflow = 1;
+                }
+                base += __popcll(mn[q]);
+            }
+        }
+        if (cq) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_qcnt[nxt], cq);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (qf[q]) {
+                    const int at = base + __popcll(mq[q] & lane_lt);
+                    if (at < PG_QCAP) queue[nxt][at] = (unsigned short)h[q]; else s_overflow = 1;
+                }
+                base += __popcll(mq[q]);
+            }
+        }
+    };
+
+    // searchsorted(cdf / cdf[-1], u, 'right') over per-leaf sums src[] and per-element values val(i): exclusive scan of the
+    // leaf sums, the leaf holding u * sum, the position inside it.  s_pick = {index, 1 if u clears both neighbouring cdf
+    // steps by margin_rel * sum}.  All comparisons are made on cdf * sum against u * sum (no divisions).
+    auto locate = [&](const double *src, double u, double margin_rel, auto val) {
+        double incl = 0.0, mine = 0.0;
+        if (tid < PG_MAX_LEAVES) {
+            mine = tid < n_leaves ? src[tid] : 0.0;
+            incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+        }
+        if (tid == 0) s_leaf = 0;
+        __syncthreads();
+        if (tid < PG_MAX_LEAVES) {
+            double base = 0.0;
+            for (int w = 0; w < wave; ++w) base += wave_tot[w];
+            if (tid < n_leaves) leaf_e[tid] = base + (incl - mine);
+            if (tid == n_leaves - 1) leaf_e[n_leaves] = base + incl;
+        }
+        __syncthreads();
+        const double S = leaf_e[n_leaves];
+        const double target = u * S;
+        if (tid < n_leaves && leaf_e[tid] <= target) atomicMax(&s_leaf, tid);       // leaf_e[0] = 0 <= target
+        __syncthreads();
+        if (wave == 0) {
+            const int L = s_leaf;
+            const bool full = L < pl.tail_first_leaf;
+            const int32_t b0 = full ? L * PW_BLOCK : pl.leaf_start[L];
+            const int len = full ? PW_BLOCK : pl.leaf_len[L];
+            const int i0 = 2 * lane, i1 = 2 * lane + 1;
+            const float x0 = i0 < len ? dmin[b0 + i0] : 0.0f, x1 = i1 < len ? dmin[b0 + i1] : 0.0f;
+            const double q0 = i0 < len ? val(x0) : 0.0;
+            const double q1 = i1 < len ? val(x1) : 0.0;
+            double inc = q0 + q1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            const double c1 = leaf_e[L] + inc, c0 = leaf_e[L] + (inc - q1);
+            const bool le0 = i0 < len && c0 <= target, le1 = i1 < len && c1 <= target;
+            const int count = __popcll(__ballot(le0)) + __popcll(__ballot(le1));
+            // c is non-decreasing: the largest c <= target is element count-1 (or the previous leaf's end), the smallest
+            // c > target is element count
+            const int lo_i = count - 1, hi_i = count;
+            const double lo_v = __shfl((lo_i & 1) ? c1 : c0, (lo_i >> 1) & 63, 64);
+            const double hi_v = __shfl((hi_i & 1) ? c1 : c0, (hi_i >> 1) & 63, 64);
+            if (lane == 0) {
+                const double lower = count > 0 ? lo_v : leaf_e[L];
+                const int32_t idx = b0 + count;
+                const double margin = margin_rel * S;
+                s_pick[0] = idx;
+                s_pick[1] = (count < len && idx < n && S > 0.0 && S < 1e37 && (target - lower > margin) && (hi_v - target > margin)) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    };
+
+    if (prof && threadIdx.x == 0) pt = __builtin_amdgcn_s_memtime();
+    for (int32_t t = it0; t < it1; ++t) {
+        // ---- solve from centers[t]: forget the previous cell, seed the table with the source ----
+        {
+            const int32_t prev = s_entries < PG_TOUCH ? s_entries : PG_TOUCH;
+            for (int i = tid; i < prev; i += PG_THREADS) { const unsigned sl = touched[i]; h_key[sl] = PG_EMPTY; h_dist[sl] = 0x7ff0000000000000ull; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned src = (unsigned)centers[t];
+            const unsigned h = (src * 2654435761u) >> 19;
+            h_key[h] = src;
+            h_dist[h] = 0ull;
+            queue[0][0] = (unsigned short)h;
+            touched[0] = (unsigned short)h;
+            s_qcnt[0] = 1; s_qcnt[1] = 0; s_entries = 1; s_overflow = 0;
+        }
+        __syncthreads();
+        GEO_STAMP(8)
+        int cur = 0;
+        int32_t sweeps = 0;
+        for (;;) {
+            const int32_t cnt = s_qcnt[cur];
+            if (cnt == 0 || s_overflow) break;
+            if (prof && tid == 0) { pacc[6] += 1; pacc[7] += cnt; }
+            for (int32_t i = tid; i < cnt; i += PG_THREADS) atomicAnd(&h_key[queue[cur][i]], PG_MASK);   // dequeue marks
+            if (tid == 0) { s_qcnt[cur ^ 1] = 0; s_nseg = 0; }
+            __syncthreads();
+            GEO_STAMP(9)
+            // The frontier in tiles of PG_TILE nodes.  Thread per node: row bounds + distance into LDS and one descriptor
+            // per 32-entry segment of its row into the tile's segment list (one round trip for the whole tile).  Then 32
+            // lanes per segment, four segments per half wave at a time: 128 segments' entries and the d_min of their far
+            // ends are in flight together (two dependent round trips per pass), whatever the degrees are.
+            for (int32_t base = 0; base < cnt; base += PG_TILE) {
+                const int m = cnt - base < PG_TILE ? cnt - base : PG_TILE;
+                if (tid < PG_TILE) {                                   // waves 0 .. PG_TILE/64-1, whole waves
+                    int nseg = 0;
+                    if (tid < m) {
+                        const unsigned slot = queue[cur][base + tid];
+                        const int32_t u = (int32_t)(h_key[slot] & PG_MASK);
+                        n_du[tid] = __longlong_as_double((long long)h_dist[slot]);
+                        const int32_t e0 = indptr[u], e1 = indptr[u + 1];
+                        n_e0[tid] = e0;
+                        n_e1[tid] = e1;
+                        nseg = (e1 - e0 + 31) >> 5;
+                    }
+                    int incl = nseg;                                   // wave scan of the segment counts, one tail update per wave
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += o;
+                    }
+                    const int wtot = __shfl(incl, 63, 64);
+                    int sbase = 0;
+                    if (lane == 0 && wtot) sbase = atomicAdd(&s_nseg, wtot);
+                    sbase = __builtin_amdgcn_readfirstlane(sbase) + incl - nseg;
+                    for (int k = 0; k < nseg; ++k)
+                        if (sbase + k < PG_SEGCAP) segs[sbase + k] = (unsigned)tid | ((unsigned)k << 8); else s_overflow = 1;
+                }
+                __syncthreads();
+                GEO_STAMP(10)
+                const int nseg_all = s_nseg < PG_SEGCAP ? s_nseg : PG_SEGCAP;
+                for (int sw = wave * 8; sw < nseg_all; sw += (PG_THREADS / 64) * 8) {   // wave-uniform trip count
+                    if (*(volatile int32_t *)&s_overflow) break;
+                    const int s0 = sw + 4 * half;
+                    int32_t v[4], en[4];
+                    float w[4], dv[4];
+                    double cand[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool valid = s0 + q < nseg_all;
+                        const unsigned desc = valid ? segs[s0 + q] : 0u;
+                        const int j = desc & 255u;
+                        en[q] = n_e0[j] + (int32_t)((desc >> 8) << 5) + sub;
+                        ok[q] = valid && en[q] < n_e1[j];
+                        cand[q] = n_du[j];
+                        v[q] = ok[q] ? indices[en[q]] : 0;
+                        w[q] = ok[q] ? (WEIGHTED ? weights[en[q]] : 1.0f) : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { dv[q] = ok[q] ? dmin[v[q]] : 0.0f; cand[q] += (double)w[q]; }
+                    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GEO_STAMP(12) }
+                    relax4(ok, v, cand, dv, cur ^ 1);
+                    if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GEO_STAMP(13) }
+                }
+                __syncthreads();
+                if (s_entries > PG_HASH_MAX) s_overflow = 1;           // same value in every thread after the barrier
+                if (tid == 0) s_nseg = 0;
+                __syncthreads();
+                GEO_STAMP(11)
+            }
+            if (++sweeps >= 4094) s_overflow = 1;
+            cur ^= 1;
+        }
+        if (s_overflow) {                                         // cell too large for the table: nothing was applied
+            if (tid == 0) { ctl->abort_iter = t; ctl->abort_reason = 4; }
+            break;
+        }
+        GEO_STAMP(0)
+        // ---- apply: d_min / argmin (kmeans_optimized.py:44 + single-pass assignment), dirty leaves ----
+        {
+            const int32_t cnt = s_entries;
+            for (int i = tid; i < cnt; i += PG_THREADS) {
+                const unsigned sl = touched[i];
+                const int32_t v = (int32_t)(h_key[sl] & PG_MASK);
+                const float x = (float)__longlong_as_double((long long)h_dist[sl]);
+                if (x < dmin[v]) {
+                    dmin[v] = x;
+                    argmin[v] = t;
+                    const int leaf = v < pl.tail_start ? ((v >> 13) << 6) + ((v & 8191) >> 7) : (int)pl.tail_leaf[v - pl.tail_start];
+                    dirty[leaf] = 1;
+                }
+            }
+        }
+        if (tid == 0) { s_ndirty = 0; *progress = t + 1; }
+        __syncthreads();                                          // stores of this workgroup are visible to its later loads
+        if (t + 1 >= n_centers_total) break;                      // last centre: applied, no draw
+        for (int j0 = wave * 64; j0 < n_leaves; j0 += PG_THREADS) {                    // wave-uniform; list tail once per wave
+            const int j = j0 + lane;
+            const bool d = j < n_leaves && dirty[j];
+            if (d) dirty[j] = 0;
+            const unsigned long long md = __ballot(d);
+            if (md) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ndirty, __popcll(md));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (d) dirty_list[base + __popcll(md & lane_lt)] = (unsigned short)j;
+            }
+        }
+        __syncthreads();
+        GEO_STAMP(1)
+        // ---- leaves that changed: numpy's float32 leaf sum (8 strided accumulators: the leaf level of its add.reduce
+        //      tree, kept current for exact draws) and the fp64 sum of the same weights (the approximate cdf) ----
+        {
+            const int j = tid & 7;
+            const int nd = s_ndirty;
+            for (int i = tid >> 3; i < nd; i += PG_THREADS / 8) {
+                const int leaf = dirty_list[i];
+                const bool full = leaf < pl.tail_first_leaf;
+                const float *a = dmin + (full ? leaf * PW_BLOCK : pl.leaf_start[leaf]);
+                const int len = full ? PW_BLOCK : pl.leaf_len[leaf];
+                const int m8 = len - (len % 8);
+                float r = 0.0f;
+                double acc = 0.0;
+                if (len == PW_BLOCK) {                            // all 16 loads of the lane in flight together
+                    float x[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) x[q] = a[8 * q + j];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) x[q] = __fmul_rn(x[q], x[q]);
+                    r = x[0];
+                    acc = (double)x[0];
+#pragma unroll
+                    for (int q = 1; q < 16; ++q) { r = __fadd_rn(r, x[q]); acc += (double)x[q]; }
+                } else if (len >= 8) {
+                    r = __fmul_rn(a[j], a[j]);
+                    acc = (double)r;
+                    for (int q = 8; q < m8; q += 8) { const float wq = __fmul_rn(a[q + j], a[q + j]); r = __fadd_rn(r, wq); acc += (double)wq; }
+                }
+                float o = __shfl_down(r, 1, 8);
+                if ((j & 1) == 0) r = __fadd_rn(r, o);
+                o = __shfl_down(r, 2, 8);
+                if ((j & 3) == 0) r = __fadd_rn(r, o);
+                o = __shfl_down(r, 4, 8);
+                acc += __shfl_down(acc, 1, 8);
+                acc += __shfl_down(acc, 2, 8);
+                acc += __shfl_down(acc, 4, 8);
+                if (j == 0) {
+                    r = __fadd_rn(r, o);
+                    if (len < 8) {
+                        r = 0.0f;
+                        acc = 0.0;
+                        for (int q = 0; q < len; ++q) { const float wq = __fmul_rn(a[q], a[q]); r = __fadd_rn(r, wq); acc += (double)wq; }
+                    } else {
+                        for (int q = m8; q < len; ++q) { const float wq = __fmul_rn(a[q], a[q]); r = __fadd_rn(r, wq); acc += (double)wq; }
+                    }
+                    tree[leaf] = r;
+                    leaf_a[leaf] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        GEO_STAMP(2)
+        // ---- draw, first on the un-normalised weights: cdf[j] / cdf[-1] of RandomState.choice differs from
+        //      sum_{i<=j} w_i / sum_i w_i by less than 2 * 2^-24 + N * 2^-52 (each p_i = fl32(w_i / total) is within 2^-24
+        //      of w_i / total, the fp64 cumsum within N * 2^-53): if u clears both neighbouring steps of the approximate
+        //      cdf by KPP_APPROX_MARGIN the index is numpy's, and neither total nor any p_i was needed ----
+        const double u = u_dev[t];
+        locate(leaf_a, u, KPP_APPROX_MARGIN + tol, [](float x) { return (double)__fmul_rn(x, x); });
+        GEO_STAMP(3)
+        if (!s_pick[1]) {
+            // ---- exact draw: numpy's float32 add.reduce (tree levels over the current leaf sums, chunk roots in order),
+            //      p = float64(w / total) per leaf, the same search with the fp64-scan tolerance only ----
+            for (int lv = 0; lv < pl.n_levels; ++lv) {
+                for (int j = s_level_off[lv] + tid; j < s_level_off[lv + 1]; j += PG_THREADS)
+                    tree[n_leaves + j] = __fadd_rn(tree[t_l[j]], tree[t_r[j]]);
+                __syncthreads();
+            }
+            if (tid == 0) {
+                float total = 0.0f;
+                for (int c = 0; c < pl.n_chunks; ++c) total = __fadd_rn(total, tree[s_chunk_root[c]]);
+                s_total = total;
+            }
+            __syncthreads();
+            const float total = s_total;
+            if (!(total > 0.0f)) {                                // degenerate weights: the solve IS applied, the draw is not
+                if (tid == 0) { ctl->abort_iter = t; ctl->abort_reason = 3; }
+                break;
+            }
+            {
+                const int j = tid & 7;
+                const int g = tid >> 3;
+                // full leaves: each of the 8 lanes takes 16 consecutive elements as four 16-byte loads
+                for (int leaf = g; leaf < pl.tail_first_leaf; leaf += PG_THREADS / 8) {
+                    const float4 *a = reinterpret_cast<const float4 *>(dmin + (size_t)leaf * PW_BLOCK) + 4 * j;
+                    float4 xa[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xa[q] = a[q];
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc += (double)__fdiv_rn(__fmul_rn(xa[q].x, xa[q].x), total) + (double)__fdiv_rn(__fmul_rn(xa[q].y, xa[q].y), total);
+                        acc += (double)__fdiv_rn(__fmul_rn(xa[q].z, xa[q].z), total) + (double)__fdiv_rn(__fmul_rn(xa[q].w, xa[q].w), total);
+                    }
+                    acc += __shfl_down(acc, 1, 8);
+                    acc += __shfl_down(acc, 2, 8);
+                    acc += __shfl_down(acc, 4, 8);
+                    if (j == 0) leaf_q[leaf] = acc;
+                }
+                for (int leaf = pl.tail_first_leaf + g; leaf < n_leaves; leaf += PG_THREADS / 8) {   // last (partial) numpy chunk
+                    const float *a = dmin + pl.leaf_start[leaf];
+                    const int len = pl.leaf_len[leaf];
+                    double acc = 0.0;
+                    for (int q = j; q < len; q += 8) acc += (double)__fdiv_rn(__fmul_rn(a[q], a[q]), total);
+                    acc += __shfl_down(acc, 1, 8);
+                    acc += __shfl_down(acc, 2, 8);
+                    acc += __shfl_down(acc, 4, 8);
+                    if (j == 0) leaf_q[leaf] = acc;
+                }
+            }
+            __syncthreads();
+            locate(leaf_q, u, tol, [total](float x) { return (double)__fdiv_rn(__fmul_rn(x, x), total); });
+            if (prof && tid == 0) pacc[5] += 1;
+            GEO_STAMP(4)
+            if (!s_pick[1]) {                                     // u within rounding reach of a cdf step: host repeats the draw
+                if (tid == 0) { ctl->abort_iter = t; ctl->abort_reason = 2; }
+                break;
+            }
+        }
+        if (tid == 0) {
+            centers[t + 1] = s_pick[0];
+            is_center[s_pick[0]] = 1;
+        }
+        __syncthreads();
+    }
+    if (prof && threadIdx.x == 0)
+        for (int k = 0; k < 14; ++k) prof[k] = pacc[k];
+#undef GEO_STAMP
+}
+
 // ------------------------------------------------------------------ host: numpy's reduction tree
 struct PwPlan {
     std::vector<int32_t> leaf_start, leaf_len, node_l, node_r, node_level, chunk_root;
@@ -615,6 +1118,8 @@ struct KppWs {
     DevPlan plan;
     int32_t *plan_blob;
     size_t plan_ints;
+    uint16_t *tail_leaf;                   // resident chain: leaf of the nodes of the last (partial) numpy chunk
+    int32_t *progress;
 };
 
 size_t plan_ints_bound(int32_t n) {
@@ -641,7 +1146,9 @@ bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
     o->plan_ints = plan_ints_bound(n);
     o->plan_blob = ar.take<int32_t>(o->plan_ints);
     o->plan.val = ar.take<float>(o->plan_ints);
-    return o->plan.val != nullptr;
+    o->tail_leaf = ar.take<uint16_t>(NP_BUFSIZE);
+    o->progress = ar.take<int32_t>(4);
+    return o->progress != nullptr;
 }
 
 }  // namespace
@@ -651,8 +1158,10 @@ extern "C" size_t geo_kpp_workspace_bytes(int32_t n) {
     const size_t tiles = ((size_t)n + SCAN_TILE - 1) / SCAN_TILE;
     return geo::align_up(4 * sizeof(KppCtl)) + geo::align_up(4 * sizeof(KppState)) + 3 * geo::align_up((size_t)n * 8) + 2 * geo::align_up((tiles + 1) * 8) +
            5 * geo::align_up((size_t)n * 4) + 2 * geo::align_up(FINISH_GRID * 4) +
-           2 * geo::align_up(plan_ints_bound(n) * 4) + 4096;
+           2 * geo::align_up(plan_ints_bound(n) * 4) + geo::align_up(NP_BUFSIZE * 2) + 4096;
 }
+
+extern "C" int32_t geo_kpp_resident_max_nodes(void) { return PG_MAX_NODES; }
 
 extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
                              int32_t *centers, uint8_t *is_center, float *dmin, int32_t *argmin, const double *u_host,
@@ -665,8 +1174,12 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     GEO_REQUIRE((size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8 <= 64 * 1024, "geo_kpp_chain: n too large for the pick kernel");
     GEO_REQUIRE(n > 0 && 0 <= it0 && it0 <= it1 && it1 <= n_centers_total, "geo_kpp_chain: bad iteration range");
     GEO_REQUIRE(((sweeps_per_solve >= 2 && sweeps_per_solve < 4096) ||
-                 (sweeps_per_solve == 0 && assume_finite && n_centers_total <= n)) && it1 - it0 < 250000,
-                "geo_kpp_chain: sweeps_per_solve out of range (0 = step kernel: needs assume_finite and K <= n)");
+                 ((sweeps_per_solve == 0 || sweeps_per_solve == -1) && assume_finite && n_centers_total <= n)) &&
+                    it1 - it0 < 250000,
+                "geo_kpp_chain: sweeps_per_solve out of range (0 = step kernel, -1 = resident workgroup: both need "
+                "assume_finite and K <= n)");
+    GEO_REQUIRE(sweeps_per_solve != -1 || n <= PG_MAX_NODES, "geo_kpp_chain: n=%d exceeds the resident chain's %d nodes", n,
+                PG_MAX_NODES);
     GEO_REQUIRE(it1 - it0 <= 1 || u_host, "geo_kpp_chain: uniform deviates missing");
     KppWs w;
     if (!carve(ws, ws_bytes, n, &w)) {
@@ -722,26 +1235,28 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     const int g_lin = geo::grid_for(n, 256, 2048);
     // frontier sweeps: the first solves cross the whole graph, later ones only the new centre's (pruned)
     // cell, where a small grid keeps the launch itself cheap
-    const char *gcap = getenv("GEO_KPP_GRID");
-    const int g_push_big = geo::grid_for(n, 32, 2048), g_push_small = geo::grid_for(n, 32, gcap ? atoi(gcap) : 256);
+    const int g_push_big = geo::grid_for(n, 32, 2048), g_push_small = geo::grid_for(n, 32, geo::options().kpp_grid);
     const int n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     const double tol = ((double)n + 16.0) * 4.440892098500626e-16;            // (n+16) * 2^-51
     const int exact_max = assume_finite ? 0 : 1;     // with every d_min finite no maximum is needed for the draw
     kpp_fill_inf_kernel<<<g_lin, 256, 0, s>>>(w.d, n);
     kpp_max_kernel<<<FINISH_GRID, 256, 0, s>>>(w.ctl, dmin, n, w.part_max, w.part_inf);
     kpp_maxfin_kernel<<<1, 64, 0, s>>>(w.ctl, w.part_max, w.part_inf, FINISH_GRID);
-    if (it0 < it1) kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, it0, w.d, w.front[0]);
+    if (it0 < it1 && sweeps_per_solve > 0) kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, it0, w.d, w.front[0]);
     GEO_LAUNCH_CHECK();
     SumPlan spl;
     spl.leaf_start = dp.leaf_start; spl.leaf_len = dp.leaf_len; spl.node_l = dp.node_l; spl.node_r = dp.node_r;
     spl.level_off = dp.level_off; spl.chunk_root = dp.chunk_root;
     spl.n_leaves = dp.n_leaves; spl.n_levels = dp.n_levels; spl.n_chunks = dp.n_chunks; spl.val = dp.val;
-    if (sweeps_per_solve == 0 && it0 < it1) {
-        // ---- step-kernel mode: one kernel, launched until the chain reports DONE ----
-        if (n_centers_total > 1)
-            GEO_HIP_CHECK(hipMemcpyAsync(w.u_dev, u_host, (size_t)(n_centers_total - 1) * sizeof(double), hipMemcpyHostToDevice, s));
+    const bool have_u = n_centers_total > 1 && u_host;
+    if (sweeps_per_solve <= 0 && have_u)
+        GEO_HIP_CHECK(hipMemcpyAsync(w.u_dev, u_host, (size_t)(n_centers_total - 1) * sizeof(double), hipMemcpyHostToDevice, s));
+    // ---- step-kernel mode for iterations [ia, ib): one kernel, launched until the chain reports DONE ----
+    int32_t stamp_next = 1;
+    auto run_steps = [&](int32_t ia, int32_t ib, KppState *hs_out, KppCtl *hc_out) -> int {
+        kpp_begin_kernel<<<1, 64, 0, s>>>(w.ctl, centers, ia, w.d, w.front[0]);
         KppState st0;
-        st0.mode = 0; st0.t = it0; st0.sw = 0; st0.stamp = 1; st0.launches = 0; st0.pad = 0;
+        st0.mode = 0; st0.t = ia; st0.sw = 0; st0.stamp = stamp_next; st0.launches = 0; st0.pad = 0;
         GEO_HIP_CHECK(hipMemcpyAsync(w.state, &st0, sizeof(KppState), hipMemcpyHostToDevice, s));
         const int nsum = (dp.n_leaves + SUM_LEAVES - 1) / SUM_LEAVES;
         int g_small = 256;
@@ -749,7 +1264,7 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
         if (n_tiles > g_small) g_small = n_tiles;
         const size_t smem = (size_t)(n_tiles + 1) * sizeof(double);
         int64_t launched = 0;
-        int32_t batch = 64, t_now = it0;
+        int32_t batch = ib - ia == 1 ? 12 : 64, t_now = ia;
         KppState hs = st0;
         KppCtl hc;
         for (;;) {
@@ -759,12 +1274,12 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
                 if (weights)
                     kpp_step_kernel<true><<<grid, 256, smem, s>>>(w.ctl, w.state, parity, indptr, indices, weights, n, w.d, dmin,
                                                                   argmin, w.mark, w.front[0], w.front[1], centers, is_center,
-                                                                  w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, it1,
+                                                                  w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, ib,
                                                                   n_centers_total);
                 else
                     kpp_step_kernel<false><<<grid, 256, smem, s>>>(w.ctl, w.state, parity, indptr, indices, weights, n, w.d, dmin,
                                                                    argmin, w.mark, w.front[0], w.front[1], centers, is_center,
-                                                                   w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, it1,
+                                                                   w.probs, w.cdf, w.tile_sum, n_tiles, w.u_dev, tol, spl, ib,
                                                                    n_centers_total);
             }
             GEO_LAUNCH_CHECK();
@@ -773,13 +1288,77 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
             GEO_HIP_CHECK(hipStreamSynchronize(s));
             if (hs.mode == 2 || hc.abort_iter >= 0) break;
             // launches still needed ~ centres left x launches per centre so far (+10 %), at most 1024 per round trip
-            const int32_t done_centres = hs.t - it0 > 0 ? hs.t - it0 : 1;
+            const int32_t done_centres = hs.t - ia > 0 ? hs.t - ia : 1;
             const double per_centre = (double)hs.launches / done_centres;
-            const double est = (double)(it1 - hs.t) * per_centre * 1.1 + 8.0;
+            const double est = (double)(ib - hs.t) * per_centre * 1.1 + 8.0;
             batch = est > 1024.0 ? 1024 : (int32_t)est;
             t_now = hs.t;
             GEO_REQUIRE(launched < ((int64_t)1 << 31), "geo_kpp_chain: step kernel did not finish");
         }
+        stamp_next = hs.stamp + 1;
+        *hs_out = hs;
+        *hc_out = hc;
+        return GEO_OK;
+    };
+    if (sweeps_per_solve == -1 && it0 < it1) {
+        // ---- resident mode: ONE workgroup runs the iterations in a single launch; a centre whose cell outgrows the
+        //      workgroup's table (abort reason 4, nothing applied) is run by the step kernel right here, then the
+        //      resident kernel takes over again ----
+        GEO_REQUIRE(dp.n_leaves <= PG_MAX_LEAVES && M <= PG_MAX_LEAVES && dp.n_chunks <= 64 && dp.n_levels < 31,
+                    "geo_kpp_chain: reduction tree of n=%d too large for the resident chain", n);
+        ResidentPlan rp;
+        rp.leaf_start = dp.leaf_start; rp.leaf_len = dp.leaf_len; rp.node_l = dp.node_l; rp.node_r = dp.node_r;
+        rp.level_off = dp.level_off; rp.chunk_root = dp.chunk_root; rp.tail_leaf = w.tail_leaf;
+        rp.n_leaves = dp.n_leaves; rp.n_nodes = M; rp.n_levels = dp.n_levels; rp.n_chunks = dp.n_chunks;
+        rp.tail_start = (n / NP_BUFSIZE) * NP_BUFSIZE;
+        rp.tail_first_leaf = (n / NP_BUFSIZE) * (NP_BUFSIZE / PW_BLOCK);
+        std::vector<uint16_t> tail(NP_BUFSIZE, 0);
+        for (int l = rp.tail_first_leaf; l < L; ++l)
+            for (int32_t v = pp.leaf_start[l]; v < pp.leaf_start[l] + pp.leaf_len[l]; ++v) tail[v - rp.tail_start] = (uint16_t)l;
+        GEO_HIP_CHECK(hipMemcpyAsync(w.tail_leaf, tail.data(), NP_BUFSIZE * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        const bool profile = geo::options().kpp_profile != 0;                 // diagnostic runs only
+        unsigned long long *prof = profile ? reinterpret_cast<unsigned long long *>(w.cdf) : nullptr;   // cdf[] is free meanwhile
+        int32_t cur_it = it0, handed_back = 0;
+        KppCtl hc;
+        for (;;) {
+            int32_t prog0 = cur_it;
+            GEO_HIP_CHECK(hipMemcpyAsync(w.progress, &prog0, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            if (weights)
+                kpp_resident_kernel<true><<<1, PG_THREADS, 0, s>>>(w.ctl, indptr, indices, weights, n, dmin, argmin, centers,
+                                                                 is_center, w.u_dev, tol, rp, cur_it, it1, n_centers_total, w.progress, prof);
+            else
+                kpp_resident_kernel<false><<<1, PG_THREADS, 0, s>>>(w.ctl, indptr, indices, weights, n, dmin, argmin, centers,
+                                                                  is_center, w.u_dev, tol, rp, cur_it, it1, n_centers_total, w.progress, prof);
+            GEO_LAUNCH_CHECK();
+            if (profile) {
+                unsigned long long hp[14];
+                GEO_HIP_CHECK(hipMemcpyAsync(hp, prof, sizeof(hp), hipMemcpyDeviceToHost, s));
+                GEO_HIP_CHECK(hipStreamSynchronize(s));
+                fprintf(stderr, "[kpp-resident] it %d..%d cycles: solve-rest %llu (init %llu marks %llu fill %llu pass-rest %llu loads %llu relax %llu) apply %llu leaf %llu locate %llu exact-draws %llu (%llu taken) | sweeps %llu frontier nodes %llu\n",
+                        cur_it, it1, hp[0], hp[8], hp[9], hp[10], hp[11], hp[12], hp[13], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+            }
+            GEO_HIP_CHECK(hipMemcpyAsync(&hc, w.ctl, sizeof(KppCtl), hipMemcpyDeviceToHost, s));
+            GEO_HIP_CHECK(hipStreamSynchronize(s));
+            if (hc.abort_iter < 0 || hc.abort_reason != 4) break;
+            const int32_t t = hc.abort_iter;
+            ++handed_back;
+            GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, 7 * sizeof(int32_t), hipMemcpyHostToDevice, s));   // abort, frontier ring, tickets; maxf stays
+            KppState hs;
+            if (int rc = run_steps(t, t + 1, &hs, &hc)) return rc;
+            if (hc.abort_iter >= 0) break;                 // the step kernel declined too (reasons 1-3): the caller's turn
+            cur_it = t + 1;
+            if (cur_it >= it1) break;
+        }
+        status_out[0] = hc.abort_iter;
+        status_out[1] = hc.abort_reason;
+        status_out[2] = 0;                           // resident mode is only entered with d_min finite everywhere
+        status_out[3] = handed_back;                 // centres run by the step kernel
+        return GEO_OK;
+    }
+    if (sweeps_per_solve == 0 && it0 < it1) {
+        KppState hs;
+        KppCtl hc;
+        if (int rc = run_steps(it0, it1, &hs, &hc)) return rc;
         status_out[0] = hc.abort_iter;
         status_out[1] = hc.abort_reason;
         status_out[2] = hc.n_inf;

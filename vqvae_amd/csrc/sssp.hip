@@ -472,10 +472,8 @@ struct MultiWs {
 // (7-10 TB/s of gathered bytes against 9-19 TB/s).  16 is kept for calls with few sources, where it
 // avoids relaxing padded lanes.
 int choose_sb(int32_t n, int32_t n_sources) {
-    if (const char *e = getenv("GEO_SSSP_SB")) {          // experiment switch (bench/tests leave it unset)
-        const int v = atoi(e);
-        if (v == 16 || v == 64) return v;
-    }
+    const int forced = geo::options().sssp_sb;               // experiment switch (bench/tests leave it alone)
+    if (forced == 16 || forced == 64) return forced;
     if (n_sources <= 16) return 16;
     // 16-source batches pay off while one batch (n * 128 bytes) stays within reach of an XCD's 4 MiB L2
     if (n_sources >= 32 && (size_t)n * 128 <= ((size_t)12 << 20) && (size_t)n * 512 > ((size_t)6 << 20)) return 16;
@@ -542,11 +540,12 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     double *lm_d = nullptr;
     float *lm_key = nullptr;
     int32_t *lm_flags = nullptr;
-    const int act_mode = getenv("GEO_SSSP_ACT") ? atoi(getenv("GEO_SSSP_ACT")) : 1;
+    const geo::Options &opt = geo::options();
+    const int act_mode = opt.sssp_act;
     // sparse body while fewer than n/sparse_div rows moved in the previous sweep; map kept below n/map_div
-    const int sparse_div = getenv("GEO_SSSP_SPARSE_DIV") ? atoi(getenv("GEO_SSSP_SPARSE_DIV")) : 8;
-    const int map_div = getenv("GEO_SSSP_MAP_DIV") ? atoi(getenv("GEO_SSSP_MAP_DIV")) : 2;
-    const int group_mode = getenv("GEO_SSSP_GROUP") ? atoi(getenv("GEO_SSSP_GROUP")) : 1;   // 0 never, 1 auto, 2 always
+    const int sparse_div = opt.sssp_sparse_div > 0 ? opt.sssp_sparse_div : 8;
+    const int map_div = opt.sssp_map_div > 0 ? opt.sssp_map_div : 2;
+    const int group_mode = opt.sssp_group;                   // 0 never, 1 auto, 2 always
     const int32_t words = (n + 3) / 4;                       // need-map: one byte per node, in 4-byte words
     int64_t n_chunks = 0;
     if (chunked) {
@@ -579,6 +578,9 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     for (int32_t i = 0; i < n_sources; ++i) order[i] = i;
     GEO_HIP_CHECK(hipMemcpyAsync(host_sources.data(), sources, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int32_t i = 0; i < n_sources; ++i)
+        GEO_REQUIRE(host_sources[i] >= 0 && host_sources[i] < n, "geo_sssp_multi: sources[%d] = %d is outside 0..%d", i,
+                    host_sources[i], n - 1);
     if (!g_ev0) {
         GEO_HIP_CHECK(hipEventCreate(&g_ev0));
         GEO_HIP_CHECK(hipEventCreate(&g_ev1));
@@ -609,12 +611,11 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
             GEO_LAUNCH_CHECK();
         }
         // grouped solves run many sweeps that touch few rows: a smaller grid keeps the idle launches cheap
-        const char *gcap = getenv("GEO_SSSP_GROUPED_CAP");
-        const int want_cap = gcap ? atoi(gcap) : 256;
+        const int want_cap = opt.sssp_grouped_cap;
         const int cap_now = (grouped && cap > want_cap) ? want_cap : cap;
         // ... and stay with the flagged-row body whenever the need-map is there
-        const int sdiv = grouped && !getenv("GEO_SSSP_SPARSE_DIV") ? 1 : sparse_div;
-        const int mdiv = grouped && !getenv("GEO_SSSP_MAP_DIV") ? 1 : map_div;
+        const int sdiv = grouped && opt.sssp_sparse_div <= 0 ? 1 : sparse_div;
+        const int mdiv = grouped && opt.sssp_map_div <= 0 ? 1 : map_div;
         const int per_batch = chunked ? geo::grid_for(n_chunks, 16, cap_now > 0 ? cap_now : 1)
                                       : geo::grid_for(n, nodes_per_block, cap > 0 ? cap : 1);
         const unsigned grid = (unsigned)per_batch * (unsigned)gs * (unsigned)groups;
@@ -647,7 +648,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                 else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
                 GEO_LAUNCH_CHECK();
-                if (chunked && getenv("GEO_SSSP_TRACE")) {            // experiment: sampled improvement counts per sweep
+                if (chunked && opt.sssp_trace) {            // experiment: sampled improvement counts per sweep
                     std::vector<int32_t> hc(nb);
                     GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)(sweeps % 4) * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));
                     long long tot = 0, neg = 0;

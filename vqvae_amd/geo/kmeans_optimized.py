@@ -11,6 +11,7 @@ structure instead -- one device solve + one numpy draw on the downloaded d_min p
 the tests compare both.
 """
 import os
+import time
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -27,6 +28,12 @@ def _to_device_graph(W) -> DeviceCSR:
         return W
     W = ensure_valid_graph(W)
     return DeviceCSR.from_scipy(_pull_structure(W, directed=False), device())
+
+
+# Tuning switches of the chain, read ONCE at import (tests flip them through _KNOBS, bench leaves them alone).
+_KNOBS = {"resident": os.environ.get("GEO_KPP_RESIDENT", "1") != "0",
+          "resident_from": int(os.environ.get("GEO_KPP_RESIDENT_FROM", "32")),
+          "log": os.environ.get("GEO_KPP_LOG", "0") == "1"}
 
 
 class _Chain:
@@ -149,21 +156,41 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     # budget from what the previous one needed.  Once d_min is finite everywhere (after the first centre on a
     # connected graph) the rest of the chain is ONE kernel launched over and over that always does "the next
     # step" (csrc/kpp.hip, kpp_step_kernel): no budget, no launch spent on an empty frontier.
+    # Later centres have small cells (~N/t nodes): from RESIDENT_FROM on, the chain runs inside ONE resident
+    # workgroup (kpp_resident_kernel), a single launch for all remaining centres; a cell that outgrows its LDS table
+    # comes back with reason 4 and that one centre is run by the step kernel.
     fixed = os.environ.get("GEO_KPP_SWEEPS")
     budget, seg, cap = (int(fixed) if fixed else 16), 1, 4094
     finite = False
+    resident_ok = _KNOBS["resident"] and N <= lib.geo_kpp_resident_max_nodes()
+    one_step_at = -1                                     # iteration the resident kernel handed back (reason 4)
     status = np.zeros(4, dtype=np.int32)
     while it < it1:
         step_mode = finite and not fixed and K <= N
-        seg_end = it1 if step_mode else min(it1, it + seg)
+        resident = step_mode and resident_ok and it >= min(_KNOBS["resident_from"], it1) and it != one_step_at
+        if resident:
+            seg_end = it1
+        elif step_mode:
+            seg_end = it + 1 if it == one_step_at else (min(it1, _KNOBS["resident_from"]) if resident_ok and it < _KNOBS["resident_from"] else it1)
+        else:
+            seg_end = min(it1, it + seg)
+        t_call = time.perf_counter()
         with torch.cuda.device(dev):
             _lib.check(lib.geo_kpp_chain(ptr(G.indptr), ptr(G.indices), ptr(G.data), N, ptr(centers_d),
                                          ptr(is_center), ptr(chain.dmin), ptr(chain.arg), u.ctypes.data, it, seg_end,
-                                         K, 0 if step_mode else budget, 1 if finite else 0, ptr(ws), ws.numel(),
-                                         status.ctypes.data, stream_ptr()),
+                                         K, (-1 if resident else 0) if step_mode else budget, 1 if finite else 0, ptr(ws),
+                                         ws.numel(), status.ctypes.data, stream_ptr()),
                        "geo_kpp_chain")
         t, reason, used = int(status[0]), int(status[1]), int(status[3])
+        if _KNOBS["log"]:
+            import sys
+            print(f"[kpp-log] it {it}..{seg_end} mode {'resident' if resident else 'step' if step_mode else budget} -> "
+                  f"abort {t} reason {reason} used {used} {1e3 * (time.perf_counter() - t_call):.2f} ms", file=sys.stderr)
         finite = finite or int(status[2]) == 0          # inf entries only ever disappear from d_min
+        if reason == 4:                                  # cell too large for the resident table: that centre by step kernel
+            chain.solves += t - it
+            it, one_step_at = t, t
+            continue
         if t < 0:
             chain.solves += seg_end - it
             it = seg_end

@@ -129,8 +129,9 @@ class DecoderExport:
         d.out_size = {1: 32, 3: 28}[seq[6].padding[0]]
         if isinstance(norm, nn.BatchNorm2d):
             d.norm, d.eps = 1, norm.eps
-            # batch statistics are used when training, or when no running statistics are tracked
-            d.bn_train = 1 if (dec.training and norm.training) or norm.running_mean is None else 0
+            # batch statistics are used when the NORM layer is in training mode (torch looks at the layer's own flag, not
+            # at its parent's), or when no running statistics are tracked
+            d.bn_train = 1 if norm.training or norm.running_mean is None else 0
             if norm.weight is None:
                 ones = {t: torch.ones(c, device=dev) for t, c in (("1", d.c1), ("2", d.c2))}
                 for t in ("1", "2"):
