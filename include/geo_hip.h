@@ -69,7 +69,8 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
 
 /* Device time (ms, HIP events on the call's stream) spent in the relaxation sweeps of the last
  * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
- * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel. */
+ * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel,
+ * 2032 for the exact 32-bit fixed-point kernel (32 sources per row). */
 int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
 
 /* One source; fused k-means++ bookkeeping of kmeans_optimized.py:43-44 and the single-pass

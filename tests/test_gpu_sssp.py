@@ -267,3 +267,72 @@ def test_resident_chain_equals_step_kernel_and_oracle():
                 assert qe == qo, tag
     finally:
         km._KNOBS.update(saved)
+
+
+def _with_option(name, value, fn):
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.geo_set_option(name, value), "geo_set_option")
+    try:
+        return fn()
+    finally:
+        lib.geo_set_option(name, 1)
+
+
+def test_fixed_point_solve_equals_fp64_solve_and_oracle():
+    """The 32-bit fixed-point multi-source kernel (32 sources per row; exact while the weights span few binades and no
+    distance reaches 2^32 units) against the fp64 kernels and the oracle: distances, predecessors, column minimum and
+    first-row argmin; weighted, unweighted and duplicate sources."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from vqvae_amd import _lib
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import _pull_structure, dijkstra_multi_source, sssp_multi_device
+    n = 20011
+    W, _ = okn.build_knn_graph(latents(n, 16, 11), k=10, mode="distance", sym="union")
+    src = np.random.RandomState(9).choice(n, 77, replace=False)
+    src = np.concatenate([src, src[[5, 60]]])
+    Do, Po = osp.dijkstra_multi_source(W, src, return_predecessors=True)
+    for u32 in (1, 0):
+        D, P = _with_option(b"sssp_u32", u32, lambda: dijkstra_multi_source(W, src, return_predecessors=True))
+        np.testing.assert_array_equal(D, Do, err_msg=f"u32={u32}")
+        assert np.mean(P == Po) > 0.999                       # parents differ only where two are equally good
+        np.testing.assert_array_equal((P < 0), (Po < 0))
+        rows, cols = np.nonzero(np.isfinite(Do) & (P >= 0))      # ... and every parent is tight
+        w_pv = np.asarray(W[P[rows, cols], cols]).ravel().astype(np.float64)
+        assert np.all(np.abs(Do[rows, P[rows, cols]].astype(np.float64) + w_pv - Do[rows, cols]) <= 1e-5 * (1 + Do[rows, cols]))
+    dev = device()
+    G = DeviceCSR.from_scipy(_pull_structure(W, False), dev)
+    st = torch.from_numpy(src.astype(np.int32)).to(dev)
+    _, _, dmin, arg, _ = _with_option(b"sssp_u32", 1, lambda: sssp_multi_device(G, st, want_D=False, want_min=True))
+    layout = _lib.load().geo_sssp_last_profile(None, None)
+    assert layout == 2032, layout                                  # the fixed-point kernel really ran
+    np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+    np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+    Du = _with_option(b"sssp_u32", 1, lambda: dijkstra_multi_source(W, src[:40], unweighted=True))
+    np.testing.assert_array_equal(Du, osp.dijkstra_multi_source(W, src[:40], unweighted=True))
+
+
+def test_fixed_point_solve_declines_and_falls_back():
+    """Weights spanning too many binades (not representable in 28-bit units) and distances that overflow 2^32 units:
+    the call is answered by the fp64 kernels, bit-equal to the oracle."""
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from vqvae_amd import _lib
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source
+    n = 20011
+    W, _ = okn.build_knn_graph(latents(n, 16, 11), k=10, mode="distance", sym="union")
+    Wide = W.copy()
+    Wide.data = (Wide.data * np.where(np.arange(Wide.nnz) % 7 == 0, 1e-4, 1.0)).astype(np.float32)
+    Wide = Wide.maximum(Wide.T).tocsr()                            # keep it symmetric
+    src = np.random.RandomState(4).choice(n, 48, replace=False)
+    np.testing.assert_array_equal(dijkstra_multi_source(Wide, src), osp.dijkstra_multi_source(Wide, src))
+    assert _lib.load().geo_sssp_last_profile(None, None) < 2000    # declined: 1e-4 x spread needs > 28 bits
+    # a long unit-weight path: 13 000 hops x 2^23 units overflows 32 bits -> saturates -> fp64 takes over
+    m = 13000
+    L = line_graph(m)
+    ls = np.arange(0, m, m // 40)[:40]
+    got = _with_option(b"sssp_group", 0, lambda: dijkstra_multi_source(L, ls))
+    np.testing.assert_array_equal(got, osp.dijkstra_multi_source(L, ls))
+    assert _lib.load().geo_sssp_last_profile(None, None) < 2000

@@ -16,6 +16,7 @@ const OptionName kOptionNames[] = {
     {"sssp_group", "GEO_SSSP_GROUP", &Options::sssp_group},
     {"sssp_grouped_cap", "GEO_SSSP_GROUPED_CAP", &Options::sssp_grouped_cap},
     {"sssp_trace", "GEO_SSSP_TRACE", &Options::sssp_trace},
+    {"sssp_u32", "GEO_SSSP_U32", &Options::sssp_u32},
     {"knn_filter", "GEO_KNN_FILTER", &Options::knn_filter},
     {"kpp_grid", "GEO_KPP_GRID", &Options::kpp_grid},
     {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},

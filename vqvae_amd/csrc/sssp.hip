@@ -80,17 +80,17 @@ __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restr
                                                          const int32_t *__restrict__ indices,
                                                          const float *__restrict__ weights, int32_t n, int32_t nb,
                                                          int32_t blocks_per_batch, int32_t gs, double *dist,
-                                                         int32_t *flags, int prev, int cur, int next, int first) {
+                                                         int32_t *flags, int prev, int cur, int next, int first, int cs) {
     constexpr int NPW = 64 / SBT;            // nodes per wave
     constexpr int NPB = NPW * WAVES_PER_BLOCK;
     const int bid = blockIdx.x;
     if (bid == 0)
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * cs + i] = 0;
     const int group = bid / (gs * blocks_per_batch);          // gs = min(nb, 8) batches share a block group
     const int b = group * gs + (bid % gs);
     const int xb = (bid % (gs * blocks_per_batch)) / gs;
     if (b >= nb) return;
-    if (!first && flags[prev * nb + b] == 0) return;   // this batch already reached its fixed point
+    if (!first && flags[prev * cs + b] == 0) return;   // this batch already reached its fixed point
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void sweep_multi_kernel(const int32_t *__restr
             any = true;
         }
     }
-    if (__any(any) && lane == 0) flags[cur * nb + b] = 1;
+    if (__any(any) && lane == 0) flags[cur * cs + b] = 1;
 }
 
 // ---- 16-source batches, work item = one 16-edge chunk of one node's row -------------------------
@@ -206,20 +206,20 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
                                                            uint32_t *__restrict__ bits_cur, int32_t words, int prev,
                                                            int cur, int next, int first, int act_mode,
                                                            int sparse_div, int map_div, int c_pprev, int c_prev,
-                                                           int c_cur, int c_clear) {
+                                                           int c_cur, int c_clear, int cs) {
     const int bid = blockIdx.x;
     if (bid == 0)
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * nb + i] = 0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * cs + i] = 0;
     const int group = bid / (gs * blocks_per_batch);
     const int b = group * gs + (bid % gs);
     const int xb = (bid % (gs * blocks_per_batch)) / gs;
     if (b >= nb) return;
-    if (!first && flags[prev * nb + b] == 0) return;                     // fixed point reached for this batch
+    if (!first && flags[prev * cs + b] == 0) return;                     // fixed point reached for this batch
     // visiting only flagged rows pays when few rows moved (first sweeps, last sweeps): `counts` holds a
     // 1-in-16 block sample of the number of improved (node, source) pairs of the previous sweep
     // counts[.] >= 0: sampled count, map written;  < 0: -(sampled count), map NOT written by that sweep
-    const int32_t cp = first ? 0 : counts[c_prev * nb + b];
-    const int32_t cpp = first ? 0 : counts[c_pprev * nb + b];
+    const int32_t cp = first ? 0 : counts[c_prev * cs + b];
+    const int32_t cpp = first ? 0 : counts[c_pprev * cs + b];
     const int32_t est_prev = (cp >= 0 ? cp : -cp) * 16;
     // expected improvements of THIS sweep: last sweep's count times its growth over the sweep before (a front
     // that is still spreading multiplies by up to the mean degree per sweep; a converging solve shrinks)
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
     // flagging costs a scattered byte store per edge of every improved row: keep it only while few rows move
     const bool write_map = sparse_sweep || (act_mode && expect * (float)map_div < (float)n * 16.0f);
     if (bid == 0)
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[c_clear * nb + i] = 0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[c_clear * cs + i] = 0;
 
     const int lane = threadIdx.x & 63;
     const int slot_in_block = threadIdx.x >> 4;              // 16 slots of 16 lanes per block
@@ -302,8 +302,265 @@ __global__ __launch_bounds__(256) void sweep_chunk16_kernel(const int32_t *__res
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) n_better += __shfl_xor(n_better, off, 64);
     if (lane == 0 && n_better > 0) {
-        flags[cur * nb + b] = 1;                                          // exact: something changed
-        if ((xb & 15) == 0) atomicAdd(&counts[c_cur * nb + b], write_map ? n_better : -n_better);   // sampled: how much
+        flags[cur * cs + b] = 1;                                          // exact: something changed
+        if ((xb & 15) == 0) atomicAdd(&counts[c_cur * cs + b], write_map ? n_better : -n_better);   // sampled: how much
+    }
+}
+
+// ---- exact 32-bit fixed point: 32 sources per 128-byte row ----------------------------------------------------
+// scipy accumulates path sums in fp64 (geo_shortest_paths.py:44-50).  Every float32 weight is an integer multiple of
+// 2^(e_min - 23), e_min the exponent of the smallest positive weight; while a path sum stays below 2^53 of those units
+// every fp64 addition along it is EXACT, so the fp64 distances are exactly the integer sums of the weights in units.
+// When the weights span few binades (24 + e_max - e_min <= 28 bits) and no distance reaches 2^32 units, the whole
+// solve runs on uint32 -- identical results, half the bytes: 32 sources share one 128-byte row, so a relaxation
+// gathers one cache line per (edge, 32 sources) instead of one per (edge, 16 sources).  Sums saturate at U_OVF; if one
+// survives to the fixed point (or the weights do not qualify) the fp64 kernels below solve the call instead.
+constexpr uint32_t U_INF = 0xffffffffu, U_OVF = 0xfffffffeu;
+
+__global__ __launch_bounds__(256) void weight_range_kernel(const float *__restrict__ w, int64_t nnz, uint32_t *__restrict__ out) {
+    uint32_t lo = 0xffffffffu, hi = 0u, bad = 0u;              // bit patterns of non-negative floats order like the floats
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        const uint32_t b = __float_as_uint(x);
+        if (!(x >= 0.0f) || b >= 0x7f800000u) bad = 1u;
+        else if (b != 0u) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; bad |= __shfl_xor(bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); if (bad) atomicOr(&out[2], 1u); }
+}
+
+__global__ __launch_bounds__(256) void weight_units_kernel(const float *__restrict__ w, int64_t nnz, int shift,
+                                                          uint32_t *__restrict__ wu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        wu[i] = w ? (uint32_t)ldexp((double)w[i], shift) : 1u;     // exact: an integer below 2^29 by the host's check
+}
+
+__global__ __launch_bounds__(256) void init_multi32_kernel(uint32_t *__restrict__ dist, const int32_t *__restrict__ src,
+                                                          int32_t n, int32_t nb) {
+    const int64_t total = (int64_t)nb * n * 32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i & 31);
+        const int64_t r = i >> 5;
+        dist[i] = (src[(r / n) * 32 + s] == (int32_t)(r % n)) ? 0u : U_INF;
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void relax_edge32u(const uint32_t *__restrict__ D, unsigned sidx, int idx, int wu, uint32_t &best) {
+    const unsigned u = (unsigned)row_bcast<J>(idx);
+    const uint32_t w = (uint32_t)row_bcast<J>(wu);
+    const uint32_t du = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(D) + ((u << 7) | (sidx << 2)));
+    const uint32_t sum = du + w;
+    const uint32_t cand = du >= U_OVF ? du : ((sum < du || sum >= U_OVF) ? U_OVF : sum);    // saturating, inf stays inf
+    best = cand < best ? cand : best;
+}
+
+// rows sorted by decreasing number of 16-entry chunks (counting sort: histogram, offsets, scatter)
+__global__ __launch_bounds__(256) void row_hist_kernel(const int32_t *__restrict__ chunk_cnt, int32_t n, int32_t *__restrict__ hist) {
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const int32_t c = chunk_cnt[v] < 255 ? chunk_cnt[v] : 255;
+        atomicAdd(&hist[255 - c], 1);                        // bin 0 = longest rows
+    }
+}
+__global__ void row_offsets_kernel(int32_t *hist) {       // one thread: 256 bins -> exclusive offsets, in place
+    int32_t run = 0;
+    for (int b = 0; b < 256; ++b) { const int32_t c = hist[b]; hist[b] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void row_scatter_kernel(const int32_t *__restrict__ chunk_cnt, int32_t n, int32_t *cursor,
+                                                         int32_t *__restrict__ row_order) {
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const int32_t c = chunk_cnt[v] < 255 ? chunk_cnt[v] : 255;
+        row_order[atomicAdd(&cursor[255 - c], 1)] = v;
+    }
+}
+
+// Same roles as in sweep_chunk16_kernel (dense body, flagged-row body, need-map, sampled improvement counts); a slot is
+// 32 lanes = 32 sources and takes whole rows, its two 16-lane DPP rows each hold a copy of the current 16 edges.
+__global__ __launch_bounds__(256) void sweep_chunk32u_kernel(const int32_t *__restrict__ indptr,
+                                                            const int32_t *__restrict__ indices,
+                                                            const uint32_t *__restrict__ wunits, int32_t n, int32_t nb,
+                                                            const int32_t *__restrict__ row_order,
+                                                            int32_t blocks_per_batch, int32_t gs, uint32_t *dist,
+                                                            int32_t *flags, int32_t *counts,
+                                                            const uint32_t *__restrict__ bits_prev,
+                                                            uint32_t *__restrict__ bits_cur, int32_t words, int prev,
+                                                            int cur, int next, int first, int act_mode,
+                                                            int sparse_div, int map_div, int c_pprev, int c_prev,
+                                                            int c_cur, int c_clear, int cs) {
+    const int bid = blockIdx.x;
+    if (bid == 0)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) flags[next * cs + i] = 0;
+    const int group = bid / (gs * blocks_per_batch);
+    const int b = group * gs + (bid % gs);
+    const int xb = (bid % (gs * blocks_per_batch)) / gs;
+    if (b >= nb) return;
+    if (!first && flags[prev * cs + b] == 0) return;                     // fixed point reached for this batch
+    const int32_t cp = first ? 0 : counts[c_prev * cs + b];
+    const int32_t cpp = first ? 0 : counts[c_pprev * cs + b];
+    const int32_t est_prev = (cp >= 0 ? cp : -cp) * 16;
+    const int32_t est_pprev = (cpp >= 0 ? cpp : -cpp) * 16;
+    float ratio = est_pprev > 0 ? (float)est_prev / (float)est_pprev : 32.0f;
+    ratio = ratio < 1.0f ? 1.0f : (ratio > 64.0f ? 64.0f : ratio);
+    const float expect = (float)est_prev * ratio;
+    const bool sparse_sweep = act_mode && (first || (cp >= 0 && expect * (float)sparse_div < (float)n * 32.0f));
+    const bool write_map = sparse_sweep || (act_mode && expect * (float)map_div < (float)n * 32.0f);
+    if (bid == 0)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) counts[c_clear * cs + i] = 0;
+
+    const int lane = threadIdx.x & 63;
+    const int slot_in_block = threadIdx.x >> 5;              // 8 slots of 32 lanes per block
+    const int s16 = lane & 15;                               // position in the DPP row = edge of the chunk this lane loads
+    const unsigned sidx = lane & 31;                         // source of this lane
+    const int slot_in_wave = lane >> 5;
+    uint32_t *D = dist + (size_t)b * n * 32;
+    const uint8_t *bp = reinterpret_cast<const uint8_t *>(bits_prev) + (size_t)b * words * 4;
+    uint8_t *bc = reinterpret_cast<uint8_t *>(bits_cur) + (size_t)b * words * 4;
+    int32_t n_better = 0;
+#define GEO_RELAX32_ALL()                                                                                       \
+    relax_edge32u<0>(D, sidx, idx, wb, best); relax_edge32u<1>(D, sidx, idx, wb, best);                         \
+    relax_edge32u<2>(D, sidx, idx, wb, best); relax_edge32u<3>(D, sidx, idx, wb, best);                         \
+    relax_edge32u<4>(D, sidx, idx, wb, best); relax_edge32u<5>(D, sidx, idx, wb, best);                         \
+    relax_edge32u<6>(D, sidx, idx, wb, best); relax_edge32u<7>(D, sidx, idx, wb, best);                         \
+    relax_edge32u<8>(D, sidx, idx, wb, best); relax_edge32u<9>(D, sidx, idx, wb, best);                         \
+    relax_edge32u<10>(D, sidx, idx, wb, best); relax_edge32u<11>(D, sidx, idx, wb, best);                       \
+    relax_edge32u<12>(D, sidx, idx, wb, best); relax_edge32u<13>(D, sidx, idx, wb, best);                       \
+    relax_edge32u<14>(D, sidx, idx, wb, best); relax_edge32u<15>(D, sidx, idx, wb, best)
+    if (sparse_sweep) {
+        for (int32_t v = xb * 8 + slot_in_block; v < n; v += blocks_per_batch * 8) {
+            if (bp[v] == 0) continue;                                            // slot-uniform
+            const int32_t e0 = indptr[v], e1 = indptr[v + 1];
+            const uint32_t curv = D[(unsigned)v * 32u + sidx];
+            uint32_t best = curv;
+            for (int32_t e = e0; e < e1; e += 16) {
+                const int32_t cnt = e1 - e;
+                const int idx = (s16 < cnt) ? indices[e + s16] : v;              // padding: the node itself, weight 0
+                const int wb = (s16 < cnt) ? (int)wunits[e + s16] : 0;
+                GEO_RELAX32_ALL();
+            }
+            const bool better = best < curv;
+            if (better) {
+                D[(unsigned)v * 32u + sidx] = best;                              // the only writer of this (row, source)
+                ++n_better;
+            }
+            if ((__ballot(better) >> (slot_in_wave * 32)) & 0xffffffffull)       // the row moved: flag its neighbours
+                for (int32_t e = e0 + (int)sidx; e < e1; e += 32) bc[indices[e]] = 1;
+        }
+    } else {
+        // dense sweep: a slot takes a whole row, rows in order of decreasing length (row_order: the two slots of a wave
+        // and the waves of a block run rows of about the same length).  One writer per (row, source) and sweep, so the
+        // improved distances are PLAIN stores: no atomics, no re-read of the row's own distance per chunk.
+        for (int32_t r = xb * 8 + slot_in_block; r < n; r += blocks_per_batch * 8) {
+            const int32_t v = row_order[r];
+            const int32_t e0 = indptr[v], e1 = indptr[v + 1];
+            const uint32_t curv = D[(unsigned)v * 32u + sidx];
+            uint32_t best = curv;
+            for (int32_t e = e0; e < e1; e += 16) {
+                const int32_t cnt = e1 - e;
+                const int idx = (s16 < cnt) ? indices[e + s16] : v;
+                const int wb = (s16 < cnt) ? (int)wunits[e + s16] : 0;
+                GEO_RELAX32_ALL();
+            }
+            const bool better = best < curv;
+            if (better) {
+                D[(unsigned)v * 32u + sidx] = best;
+                ++n_better;
+            }
+            if (write_map && ((__ballot(better) >> (slot_in_wave * 32)) & 0xffffffffull))   // flag ALL neighbours of v
+                for (int32_t e2 = e0 + (int)sidx; e2 < e1; e2 += 32) bc[indices[e2]] = 1;
+        }
+    }
+#undef GEO_RELAX32_ALL
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_better += __shfl_xor(n_better, off, 64);
+    if (lane == 0 && n_better > 0) {
+        flags[cur * cs + b] = 1;                                          // exact: something changed
+        if ((xb & 15) == 0) atomicAdd(&counts[c_cur * cs + b], write_map ? n_better : -n_better);   // sampled: how much
+    }
+}
+
+__device__ __forceinline__ double units_to_f64(uint32_t u, double unit) { return u == U_INF ? inf64() : (double)u * unit; }
+
+// any distance that saturated?  (checked once, at the fixed point)
+__global__ __launch_bounds__(256) void overflow_scan_kernel(const uint32_t *__restrict__ dist, int64_t total, int32_t *flag) {
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        any |= dist[i] == U_OVF;
+    if (__any(any) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+__global__ __launch_bounds__(256) void transpose_out32_kernel(const uint32_t *__restrict__ in, float *__restrict__ out,
+                                                             int32_t n, int32_t n_sources, double unit,
+                                                             const int32_t *__restrict__ row_of) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.y;
+    const int32_t v0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int vi = i >> 5, si = i & 31;
+        if (v0 + vi < n) tile[vi][si] = (float)units_to_f64(in[((size_t)b * n + v0 + vi) * 32 + si], unit);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int si = i >> 6, vi = i & 63;
+        const int32_t slot = b * 32 + si;
+        if (slot < n_sources && v0 + vi < n) out[(size_t)row_of[slot] * n + v0 + vi] = tile[vi][si];
+    }
+}
+
+__global__ __launch_bounds__(256) void colmin32_kernel(const uint32_t *__restrict__ dist, int32_t n, int32_t n_sources,
+                                                      double unit, const int32_t *__restrict__ row_of,
+                                                      float *__restrict__ dmin, int32_t *__restrict__ argmin) {
+    const int lane = threadIdx.x & 63;
+    const int32_t v = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (v >= n) return;
+    float best = __int_as_float(0x7f800000);
+    int32_t barg = 0x7fffffff;
+    for (int32_t r0 = 0; r0 < n_sources; r0 += 64) {
+        const int32_t row = r0 + lane;
+        float val = __int_as_float(0x7f800000);
+        if (row < n_sources) val = (float)units_to_f64(dist[((size_t)(row >> 5) * n + v) * 32 + (row & 31)], unit);
+        int32_t idx = row < n_sources ? row_of[row] : 0x7fffffff;     // ties: lowest row of the CALLER's order
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(val, off, 64);
+            const int32_t oi = __shfl_xor(idx, off, 64);
+            if (ov < val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (val < best || (val == best && idx < barg)) { best = val; barg = idx; }
+    }
+    if (lane == 0) {
+        if (dmin) dmin[v] = best;
+        if (argmin) argmin[v] = barg;
+    }
+}
+
+// predecessors on the integer distances: same tie rule as pred_multi_kernel
+__global__ __launch_bounds__(256) void pred_multi32_kernel(const int32_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const uint32_t *__restrict__ wunits, int32_t n, int32_t nb,
+                                                          const uint32_t *__restrict__ dist,
+                                                          const int32_t *__restrict__ src, int32_t *__restrict__ pred) {
+    const int64_t total = (int64_t)nb * n * 32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i & 31);
+        const int64_t r = i >> 5;
+        const int32_t v = (int32_t)(r % n);
+        const int32_t b = (int32_t)(r / n);
+        const uint32_t *D = dist + (size_t)b * n * 32;
+        const uint32_t dv = dist[i];
+        int32_t p = -9999;
+        uint32_t dp = U_INF;
+        if (dv < U_OVF && v != src[b * 32 + s]) {
+            for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+                const int32_t u = indices[e];
+                const uint32_t du = D[(size_t)u * 32 + s];
+                if (du < U_OVF && du + wunits[e] == dv && (du < dp || (du == dp && u < p))) { dp = du; p = u; }
+            }
+        }
+        pred[i] = p;
     }
 }
 
@@ -485,13 +742,18 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     const size_t words = ((size_t)n + 3) / 4;
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
-           geo::align_up(4 * (size_t)nb * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) + 256;
+           geo::align_up(4 * (((size_t)nb + 31) / 32 * 32) * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) +
+           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024;
 }
 
+// slots of a solve: whole batches of `sb` sources, and (for the 32-source fixed-point layout of the same buffers) of 32
+size_t padded_slots(int32_t nb, int32_t sb) { return ((size_t)nb * sb + 31) / 32 * 32; }
+
 size_t multi_bytes(int32_t n, int32_t nb, int32_t sb, bool with_pred) {
-    size_t b = geo::align_up((size_t)nb * n * sb * sizeof(double));
-    if (with_pred) b += geo::align_up((size_t)nb * n * sb * sizeof(int32_t));
-    b += geo::align_up(3 * (size_t)nb * sizeof(int32_t)) + 2 * geo::align_up((size_t)nb * sb * sizeof(int32_t));
+    const size_t slots = padded_slots(nb, sb);
+    size_t b = geo::align_up(slots * n * sizeof(double));
+    if (with_pred) b += geo::align_up(slots * n * sizeof(int32_t));
+    b += geo::align_up(3 * (((size_t)nb + 31) / 32 * 32) * sizeof(int32_t)) + 2 * geo::align_up(slots * sizeof(int32_t));
     return b;
 }
 
@@ -528,11 +790,15 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     }
     geo::Arena ar(ws, ws_bytes);
     MultiWs w;
-    w.dist = ar.take<double>((size_t)nb * n * sb);
-    w.pred = P_out ? ar.take<int32_t>((size_t)nb * n * sb) : nullptr;
-    w.flags = ar.take<int32_t>(3 * (size_t)nb);
-    w.src_pad = ar.take<int32_t>((size_t)nb * sb);
-    int32_t *row_of = ar.take<int32_t>((size_t)nb * sb);          // (batch, slot) -> row of the caller's `sources`
+    const size_t slots = padded_slots(nb, sb);
+    w.dist = ar.take<double>(slots * n);
+    w.pred = P_out ? ar.take<int32_t>(slots * n) : nullptr;
+    // rows of the flag / count rings start on their own 128-byte lines: every block reads the previous sweep's row while
+    // the current sweep's row takes stores and atomics (a shared line made alternate sweeps 3x slower at nb = 16)
+    const int cs = ((nb + 31) / 32) * 32;
+    w.flags = ar.take<int32_t>(3 * (size_t)cs);
+    w.src_pad = ar.take<int32_t>(slots);
+    int32_t *row_of = ar.take<int32_t>(slots);                    // (batch, slot) -> row of the caller's `sources`
 
     int32_t *chunk_node = nullptr, *chunk_start = nullptr;
     uint32_t *bits = nullptr;
@@ -540,6 +806,8 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     double *lm_d = nullptr;
     float *lm_key = nullptr;
     int32_t *lm_flags = nullptr;
+    uint32_t *wunits = nullptr, *wrange = nullptr;           // 32-bit fixed-point weights / their range
+    int32_t *chunk_cnt = nullptr, *row_order = nullptr, *row_hist = nullptr;
     const geo::Options &opt = geo::options();
     const int act_mode = opt.sssp_act;
     // sparse body while fewer than n/sparse_div rows moved in the previous sweep; map kept below n/map_div
@@ -550,8 +818,11 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     int64_t n_chunks = 0;
     if (chunked) {
         bits = ar.take<uint32_t>(3 * (size_t)nb * words);
-        counts = ar.take<int32_t>(4 * (size_t)nb);
+        counts = ar.take<int32_t>(4 * (size_t)cs);
         int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
+        chunk_cnt = ccnt;
+        row_order = ar.take<int32_t>((size_t)n);
+        row_hist = ar.take<int32_t>(256);
         const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
         chunk_node = ar.take<int32_t>(max_chunks);
         chunk_start = ar.take<int32_t>(max_chunks);
@@ -560,7 +831,10 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         lm_d = ar.take<double>((size_t)n);
         lm_key = ar.take<float>(2 * (size_t)nb * sb);
         lm_flags = ar.take<int32_t>(4);
-        GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags, "geo_sssp_multi: workspace carve failed");
+        wunits = ar.take<uint32_t>((size_t)(nnz > 0 ? nnz : 1));
+        wrange = ar.take<uint32_t>(4);
+        GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange,
+                    "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
         int rc = geo::exclusive_scan_i32(ccnt, coff, n, stmp, sbytes, &n_chunks, stream);
@@ -586,6 +860,123 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         GEO_HIP_CHECK(hipEventCreate(&g_ev1));
     }
     g_last_sweep_ms = 0.0;
+    // ---- exact 32-bit fixed-point solve (32 sources per row) when the weights qualify; see sweep_chunk32u_kernel ----
+    if (chunked && n_sources >= 32 && opt.sssp_u32 != 0) {
+        int shift = 0;
+        bool eligible = true;
+        if (weights) {
+            const uint32_t init[4] = {0xffffffffu, 0u, 0u, 0u};
+            uint32_t got[4];
+            GEO_HIP_CHECK(hipMemcpyAsync(wrange, init, sizeof(init), hipMemcpyHostToDevice, stream));
+            weight_range_kernel<<<geo::grid_for(nnz, 256, 1024), 256, 0, stream>>>(weights, nnz, wrange);
+            GEO_LAUNCH_CHECK();
+            GEO_HIP_CHECK(hipMemcpyAsync(got, wrange, sizeof(got), hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            if (got[2]) eligible = false;                                   // negative, NaN or infinite weight
+            else if (got[0] != 0xffffffffu) {                               // some positive weight
+                const int e_min = (int)(got[0] >> 23) - 127, e_max = (int)(got[1] >> 23) - 127;
+                eligible = (got[0] >> 23) != 0 && 24 + (e_max - e_min) <= 28;    // normal numbers, < 2^28 units each
+                shift = 23 - e_min;
+            }
+        }
+        if (eligible) {
+            const int32_t nb32 = (n_sources + 31) / 32;
+            const double unit = std::ldexp(1.0, -shift);
+            uint32_t *dist32 = reinterpret_cast<uint32_t *>(w.dist);
+            weight_units_kernel<<<geo::grid_for(nnz, 256, 2048), 256, 0, stream>>>(weights, nnz, shift, wunits);
+            GEO_HIP_CHECK(hipMemsetAsync(row_hist, 0, 256 * sizeof(int32_t), stream));
+            row_hist_kernel<<<geo::grid_for(n, 256, 256), 256, 0, stream>>>(chunk_cnt, n, row_hist);
+            row_offsets_kernel<<<1, 1, 0, stream>>>(row_hist);
+            row_scatter_kernel<<<geo::grid_for(n, 256, 256), 256, 0, stream>>>(chunk_cnt, n, row_hist, row_order);
+            GEO_LAUNCH_CHECK();
+            std::vector<int32_t> hsrc32((size_t)nb32 * 32, -1), hrow32((size_t)nb32 * 32, -1), hf(nb32), hc(2 * (size_t)nb32);
+            for (int32_t i = 0; i < n_sources; ++i) { hsrc32[i] = host_sources[i]; hrow32[i] = i; }
+            GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, hsrc32.data(), hsrc32.size() * 4, hipMemcpyHostToDevice, stream));
+            GEO_HIP_CHECK(hipMemcpyAsync(row_of, hrow32.data(), hrow32.size() * 4, hipMemcpyHostToDevice, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)cs * sizeof(int32_t), stream));
+            init_multi32_kernel<<<geo::grid_for((int64_t)nb32 * n * 32, 256 * 8), 256, 0, stream>>>(dist32, w.src_pad, n, nb32);
+            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 4 * (size_t)cs * 4, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb32 * words * 4, stream));
+            source_need_kernel<<<geo::grid_for((int64_t)n_sources * 16, 256, 256), 256, 0, stream>>>(
+                w.src_pad, n_sources, n, 32, words, indptr, indices, bits + 2 * (size_t)nb32 * words);
+            GEO_LAUNCH_CHECK();
+            const int gs32 = nb32 < 8 ? nb32 : 8, groups32 = (nb32 + gs32 - 1) / gs32;
+            const int cap32 = 65536 / (gs32 * groups32);
+            const int per_batch = geo::grid_for(n, 8, cap32 > 0 ? cap32 : 1);     // 8 row slots per block
+            const unsigned grid = (unsigned)per_batch * (unsigned)gs32 * (unsigned)groups32;
+            int32_t sweeps = 0;
+            bool done = false, give_up = false;
+            int group_len = SWEEP_GROUP;
+            while (!done && !give_up) {
+                int last_cur = 0;
+                GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
+                for (int g = 0; g < group_len; ++g, ++sweeps) {
+                    const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
+                    uint32_t *bcur = bits + (size_t)cur * nb32 * words, *bprev = bits + (size_t)prev * nb32 * words;
+                    if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb32 * words * 4, stream));
+                    sweep_chunk32u_kernel<<<grid, 256, 0, stream>>>(indptr, indices, wunits, n, nb32, row_order,
+                                                                  per_batch, gs32, dist32, w.flags, counts, bprev,
+                                                                  bcur, words, prev, cur, next, sweeps == 0, act_mode, sparse_div,
+                                                                  map_div, (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4,
+                                                                  (sweeps + 1) % 4, cs);
+                    GEO_LAUNCH_CHECK();
+                    if (opt.sssp_trace) {                              // experiment: sampled improvement counts per sweep
+                        std::vector<int32_t> tc(nb32);
+                        GEO_HIP_CHECK(hipMemcpy(tc.data(), counts + (size_t)(sweeps % 4) * cs, (size_t)nb32 * 4, hipMemcpyDeviceToHost));
+                        long long tot = 0, neg = 0;
+                        for (int32_t b = 0; b < nb32; ++b) { tot += tc[b] < 0 ? -tc[b] : tc[b]; neg += tc[b] < 0; }
+                        fprintf(stderr, "[sssp-u32] sweep %d: ~%lld improved pairs (%.1f%% of pairs), %lld/%d batches without map\n", sweeps,
+                                tot * 16, 100.0 * tot * 16 / ((double)nb32 * n * 32), neg, nb32);
+                    }
+                    last_cur = cur;
+                }
+                GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
+                GEO_HIP_CHECK(hipMemcpyAsync(hf.data(), w.flags + (size_t)last_cur * cs, (size_t)nb32 * 4, hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipMemcpyAsync(hc.data(), counts + (size_t)((sweeps + 3) % 4) * cs, (size_t)nb32 * 4, hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipMemcpyAsync(hc.data() + nb32, counts + (size_t)((sweeps + 2) % 4) * cs, (size_t)nb32 * 4, hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                float ms = 0.f;
+                GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+                g_last_sweep_ms += ms;
+                done = true;
+                for (int32_t b = 0; b < nb32; ++b) done = done && (hf[b] == 0);
+                if (!done && sweeps == SWEEP_GROUP && group_mode != 0) {
+                    // long geodesics (few pairs moved so far): the fp64 path below regroups the sources and takes over
+                    double moved = 0.0;
+                    for (int32_t b = 0; b < 2 * nb32; ++b) moved += 16.0 * (hc[b] < 0 ? -hc[b] : hc[b]);
+                    give_up = group_mode == 2 || moved < 0.25 * (double)nb32 * n * 32;
+                }
+                if (!done && sweeps > (int64_t)n + 2) give_up = true;
+                if (sweeps >= 16 && group_len < 16) group_len *= 2;
+            }
+            if (done) {
+                int32_t ovf = 0;
+                GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, sizeof(int32_t), stream));
+                overflow_scan_kernel<<<geo::grid_for((int64_t)nb32 * n * 32, 256, 2048), 256, 0, stream>>>(dist32, (int64_t)nb32 * n * 32, w.flags);
+                GEO_HIP_CHECK(hipMemcpyAsync(&ovf, w.flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                if (!ovf) {
+                    if (sweeps_out) *sweeps_out = sweeps;
+                    g_last_sweep_launches = sweeps;
+                    g_last_layout = 2032;
+                    const dim3 tg((unsigned)((n + 63) / 64), (unsigned)nb32);
+                    if (D_out) transpose_out32_kernel<<<tg, 256, 0, stream>>>(dist32, D_out, n, n_sources, unit, row_of);
+                    if (P_out) {
+                        pred_multi32_kernel<<<geo::grid_for((int64_t)nb32 * n * 32, 256, 8192), 256, 0, stream>>>(
+                            indptr, indices, wunits, n, nb32, dist32, w.src_pad, w.pred);
+                        transpose_out_kernel<int32_t, int32_t><<<tg, 256, 0, stream>>>(w.pred, P_out, n, n_sources, 32, row_of);
+                    }
+                    if (dmin_out || argmin_out)
+                        colmin32_kernel<<<(unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), 256, 0, stream>>>(
+                            dist32, n, n_sources, unit, row_of, dmin_out, argmin_out);
+                    GEO_LAUNCH_CHECK();
+                    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                    return GEO_OK;
+                }
+            }
+            g_last_sweep_ms = 0.0;                       // the fp64 solve below is the one that counts
+        }
+    }
     int32_t total_sweeps = 0;
     bool grouped = false;
     // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
@@ -600,11 +991,11 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         for (int32_t i = 0; i < n_sources; ++i) { hsrc[i] = host_sources[order[i]]; hrow[i] = order[i]; }
         GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, hsrc.data(), hsrc.size() * 4, hipMemcpyHostToDevice, stream));
         GEO_HIP_CHECK(hipMemcpyAsync(row_of, hrow.data(), hrow.size() * 4, hipMemcpyHostToDevice, stream));
-        GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)nb * sizeof(int32_t), stream));
+        GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)cs * sizeof(int32_t), stream));
         init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
         GEO_LAUNCH_CHECK();
         if (chunked) {
-            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 4 * (size_t)nb * 4, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(counts, 0, 4 * (size_t)cs * 4, stream));
             GEO_HIP_CHECK(hipMemsetAsync(bits, 0, 3 * (size_t)nb * words * 4, stream));
             source_need_kernel<<<geo::grid_for((int64_t)n_sources * 16, 256, 256), 256, 0, stream>>>(
                 w.src_pad, n_sources, n, sb, words, indptr, indices, bits + 2 * (size_t)nb * words);
@@ -630,7 +1021,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                 const int cur = sweeps % 3, prev = (sweeps + 2) % 3, next = (sweeps + 1) % 3;
 #define GEO_SWEEP(SBT, WT)                                                                                          \
     sweep_multi_kernel<SBT, WT><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, per_batch, gs, w.dist, w.flags, \
-                                                          prev, cur, next, sweeps == 0)
+                                                          prev, cur, next, sweeps == 0, cs)
                 if (chunked) {
                     uint32_t *bcur = bits + (size_t)cur * nb * words, *bprev = bits + (size_t)prev * nb * words;
                     if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb * words * 4, stream));
@@ -638,19 +1029,19 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                         sweep_chunk16_kernel<true><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                              (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
                                                                              counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv,
-                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4);
+                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4, cs);
                     else
                         sweep_chunk16_kernel<false><<<grid, 256, 0, stream>>>(indptr, indices, weights, n, nb, chunk_node, chunk_start,
                                                                               (int32_t)n_chunks, per_batch, gs, w.dist, w.flags,
                                                                               counts, bprev, bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv, mdiv,
-                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4);
+                                                                             (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4, (sweeps + 1) % 4, cs);
                 } else if (sb == 64) { if (weights) GEO_SWEEP(64, true); else GEO_SWEEP(64, false); }
                 else                 { if (weights) GEO_SWEEP(16, true); else GEO_SWEEP(16, false); }
 #undef GEO_SWEEP
                 GEO_LAUNCH_CHECK();
                 if (chunked && opt.sssp_trace) {            // experiment: sampled improvement counts per sweep
                     std::vector<int32_t> hc(nb);
-                    GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)(sweeps % 4) * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));
+                    GEO_HIP_CHECK(hipMemcpy(hc.data(), counts + (size_t)(sweeps % 4) * cs, (size_t)nb * 4, hipMemcpyDeviceToHost));
                     long long tot = 0, neg = 0;
                     for (int32_t b = 0; b < nb; ++b) { tot += hc[b] < 0 ? -hc[b] : hc[b]; neg += hc[b] < 0; }
                     fprintf(stderr, "[sssp] sweep %d: ~%lld improved pairs (%.1f%% of pairs), %lld/%d batches without map\n", sweeps,
@@ -659,13 +1050,13 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                 last_cur = cur;
             }
             GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
-            GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * nb, (size_t)nb * sizeof(int32_t),
+            GEO_HIP_CHECK(hipMemcpyAsync(hflags.data(), w.flags + (size_t)last_cur * cs, (size_t)nb * sizeof(int32_t),
                                          hipMemcpyDeviceToHost, stream));
             if (chunked) {                       // improvement counts of the last two sweeps (4-slot ring)
                 const int c_last = (sweeps + 3) % 4, c_before = (sweeps + 2) % 4;        // `sweeps` already counts them
-                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data(), counts + (size_t)c_last * nb, (size_t)nb * sizeof(int32_t),
+                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data(), counts + (size_t)c_last * cs, (size_t)nb * sizeof(int32_t),
                                              hipMemcpyDeviceToHost, stream));
-                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data() + nb, counts + (size_t)c_before * nb, (size_t)nb * sizeof(int32_t),
+                GEO_HIP_CHECK(hipMemcpyAsync(hcounts.data() + nb, counts + (size_t)c_before * cs, (size_t)nb * sizeof(int32_t),
                                              hipMemcpyDeviceToHost, stream));
             }
             GEO_HIP_CHECK(hipStreamSynchronize(stream));
