@@ -69,8 +69,8 @@ def symmetrise(N: int, indices: np.ndarray, weights: np.ndarray, sym: str) -> sp
 def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
                             sym: str = "mutual") -> Tuple[sparse.csr_matrix, Dict[str, np.ndarray]]:
     assert z.ndim == 2, "z must be (N,D)"
-    if metric != "euclidean":
-        raise NotImplementedError("oracle restates the euclidean metric only")
+    if metric not in ("euclidean", "cosine"):
+        raise NotImplementedError("oracle restates the euclidean and cosine metrics only")
     N = z.shape[0]
     if N == 0:
         return (sparse.csr_matrix((0, 0), dtype=np.float32),
@@ -79,7 +79,17 @@ def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean
     if k_eff == 0:
         return (sparse.csr_matrix((N, N), dtype=np.float32),
                 {"distances": np.empty((N, 0), np.float32), "indices": np.empty((N, 0), dtype=int)})
-    dist, idx = knn_search(z, min(k_eff + 1, N))
+    if metric == "cosine":
+        # sklearn: cosine_distances = 1 - <x/|x|, y/|y|>, clipped to [0, 2] (sklearn/metrics/pairwise.py); for unit rows
+        # that is |x^ - y^|^2 / 2, ranked here in fp64 on the float32-rounded unit rows (zero rows stay zero, as in
+        # sklearn's normalize)
+        z64 = z.astype(np.float64)
+        nrm = np.sqrt((z64 * z64).sum(axis=1, keepdims=True))
+        zn = (z64 / np.where(nrm == 0.0, 1.0, nrm)).astype(np.float32)
+        dist, idx = knn_search(zn, min(k_eff + 1, N))
+        dist = np.clip(dist * dist * 0.5, 0.0, 2.0)
+    else:
+        dist, idx = knn_search(z, min(k_eff + 1, N))
     dist, idx = drop_self(dist, idx)
     weights = dist if mode == "distance" else np.ones_like(dist)
     W = symmetrise(N, idx, weights, sym)

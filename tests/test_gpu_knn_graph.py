@@ -233,3 +233,29 @@ def test_upper_edges_and_reweight_vs_oracle():
     np.testing.assert_array_equal(gotm.indptr, refm.indptr)
     np.testing.assert_array_equal(gotm.indices, refm.indices)
     np.testing.assert_array_equal(gotm.data, refm.data)
+
+
+def test_cosine_and_other_metrics_vs_reference(golden):
+    """metric != "euclidean" ("never an error"): cosine on the HIP search over the unit rows, manhattan /
+    chebyshev through torch.cdist on the GPU; reference graphs in tests/golden/knn_metrics.npz.  An unknown metric
+    name is a ValueError, as sklearn raises."""
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph_auto
+    g = golden("knn_metrics")
+    for name, (N, d, seed) in {"g16": (2048, 16, 0), "g32": (512, 32, 1)}.items():
+        z = latents(N, d, seed)
+        for metric in ("cosine", "manhattan", "chebyshev"):
+            if metric != "cosine" and name != "g32":
+                continue
+            for mode, sym in (("distance", "union"), ("connectivity", "mutual")):
+                tag = f"{name}/{metric}/{mode}/{sym}"
+                W, info = build_knn_graph_auto(z, k=20, metric=metric, mode=mode, sym=sym)
+                W.sort_indices()
+                np.testing.assert_array_equal(W.indptr, g[f"{tag}/indptr"], err_msg=tag)
+                np.testing.assert_array_equal(W.indices, g[f"{tag}/indices"], err_msg=tag)
+                if mode == "distance":
+                    ref = g[f"{tag}/data"]
+                    assert np.abs(W.data - ref).max() <= 5e-7 * max(1.0, float(ref.max())), tag
+            np.testing.assert_array_equal(info["indices"], g[f"{name}/{metric}/nbr_indices"])
+            assert info["distances"].dtype == np.float32
+    with pytest.raises(ValueError):
+        build_knn_graph_auto(latents(64, 8, 0), k=5, metric="no-such-metric")

@@ -218,3 +218,20 @@ def test_dense_closed_form_equals_layer_by_layer(golden):
         ref = golden("metric")[f"{name}/train1/bs512"]
         rel = np.abs(om.edge_lengths_dense(sd, size, zs, ze, batch_size=512).numpy() - ref) / ref
         assert np.quantile(rel, 0.99) < 2e-6
+
+
+def test_cosine_knn_graph_equals_reference(golden):
+    """metric="cosine" (sklearn cosine_distances behind knn_graph_optimized.py:40): structure identical, weights within
+    float32 rounding of sklearn's float32 pipeline."""
+    g = golden("knn_metrics")
+    for name, (N, d, seed) in {"g16": (2048, 16, 0), "g32": (512, 32, 1)}.items():
+        z = latents(N, d, seed)
+        for mode, sym in (("distance", "union"), ("connectivity", "mutual")):
+            tag = f"{name}/cosine/{mode}/{sym}"
+            W, info = okn.build_knn_graph_auto(z, k=20, metric="cosine", mode=mode, sym=sym)
+            W.sort_indices()
+            np.testing.assert_array_equal(W.indptr, g[f"{tag}/indptr"], err_msg=tag)
+            np.testing.assert_array_equal(W.indices, g[f"{tag}/indices"], err_msg=tag)
+            if mode == "distance":
+                assert np.abs(W.data - g[f"{tag}/data"]).max() <= 5e-7
+        np.testing.assert_array_equal(info["indices"], g[f"{name}/cosine/nbr_indices"])

@@ -24,6 +24,7 @@
 #include "geo_common.h"
 #include "sssp_device.h"
 
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -33,14 +34,18 @@ constexpr int PW_BLOCK = 128;         // numpy pairwise-sum leaf size
 constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_TILE = SCAN_T * SCAN_I;
 constexpr int FINISH_GRID = 256;
 
+// Words that take atomics (frontier counts, tickets) each sit on a 128-byte line of their own, away from the words every
+// block of every launch reads (abort flag, total, margin): an atomic is executed at the memory side and drops the line
+// from the L2s, so readers of a shared line would all go to memory behind the atomics.
 struct KppCtl {
-    int32_t abort_iter, abort_reason;      // -1 / 0 while healthy; reason 1 solve, 2 margin, 3 degenerate
-    int32_t fcount[3];                     // frontier sizes, ring over sweeps
-    int32_t ticket[2];                     // "last block finishes the job" counters of the sum / draw kernels
+    int32_t abort_iter, abort_reason;      // -1 / 0 while healthy; reason 1 solve, 2 margin, 3 degenerate, 4 cell too large
     float total;
     float maxf;                            // max finite d_min (-1: none), basis of the pruning margin
     int32_t n_inf;                         // unreachable (inf) entries of d_min at the last max pass
     int32_t max_sw;                        // most sweeps any solve of this call needed (non-empty frontiers)
+    int32_t pad0[26];
+    int32_t fcount[3][32];                 // frontier sizes, ring over sweeps: [k][0]
+    int32_t ticket[2][32];                 // "last block finishes the job" counters of the sum / draw kernels: [k][0]
 };
 
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
@@ -59,9 +64,9 @@ __device__ __forceinline__ void kpp_begin(KppCtl *ctl, const int32_t *centers, i
     const int32_t src = centers[pos];
     d[src] = 0.0;
     front0[0] = src;
-    ctl->fcount[0] = 1;
-    ctl->fcount[1] = 0;
-    ctl->fcount[2] = 0;
+    ctl->fcount[0][0] = 1;
+    ctl->fcount[1][0] = 0;
+    ctl->fcount[2][0] = 0;
 }
 
 __global__ void kpp_begin_kernel(KppCtl *ctl, const int32_t *__restrict__ centers, int32_t pos, double *d,
@@ -106,7 +111,7 @@ __device__ __forceinline__ void kpp_push_body(KppCtl *ctl, const int32_t *__rest
             if (m) {
                 const int leader = __ffsll((long long)m) - 1;
                 int32_t at = 0;
-                if (lane == leader) at = atomicAdd(&ctl->fcount[next], __popcll(m));
+                if (lane == leader) at = atomicAdd(&ctl->fcount[next][0], __popcll(m));
                 at = __shfl(at, leader, 64);
                 if (queue) fout[at + __popcll(m & ((1ull << lane) - 1ull))] = v;
             }
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(256) void kpp_push_kernel(KppCtl *ctl, const int32_
                                                       const int32_t *__restrict__ fin, int32_t *__restrict__ fout,
                                                       int cur, int next, int clear, int32_t stamp_solve, int32_t sw) {
     if (ctl->abort_iter >= 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear] = 0;
-    const int32_t cnt = ctl->fcount[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fcount[clear][0] = 0;
+    const int32_t cnt = ctl->fcount[cur][0];
     if (cnt == 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0 && sw + 1 > ctl->max_sw) ctl->max_sw = sw + 1;   // launches are serial
     kpp_push_body<WEIGHTED>(ctl, indptr, indices, weights, d, dmin, mark, fin, fout, cnt, next,
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void kpp_finish_kernel(KppCtl *ctl, double *d,
                                                         int32_t *__restrict__ argmin, int32_t n, int last_next,
                                                         int32_t pos) {
     if (ctl->abort_iter >= 0) return;
-    if (ctl->fcount[last_next] != 0) {
+    if (ctl->fcount[last_next][0] != 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
         return;                                             // every block sees the same final count
     }
@@ -311,7 +316,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
             if (live) st_dev(&val[leaf], r);
         }
     }
-    if (!last_block_done(&ctl->ticket[0], nblocks)) return false;
+    if (!last_block_done(&ctl->ticket[0][0], nblocks)) return false;
     __shared__ int32_t s_nl[TREE_LDS_NODES], s_nr[TREE_LDS_NODES], s_lo[32], s_cr[64];
     const int n_levels = pl.n_levels, n_chunks = pl.n_chunks;
     const int n_nodes = pl.level_off[n_levels];
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
                                                      const int32_t *__restrict__ part_inf, int n_part, int exact_max,
                                                      float *__restrict__ probs, SumPlan pl) {
     if (ctl->abort_iter >= 0) return;
-    if (fuse_finish && ctl->fcount[last_next] != 0) {          // the solve did not converge: apply nothing
+    if (fuse_finish && ctl->fcount[last_next][0] != 0) {          // the solve did not converge: apply nothing
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->abort_iter = pos; ctl->abort_reason = 1; }
         return;
     }
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
         return;
     if (threadIdx.x == 0) {
         ctl->total = total;
-        ctl->ticket[0] = 0;
+        ctl->ticket[0][0] = 0;
         if (!(total > 0.0f)) { ctl->abort_iter = pos; ctl->abort_reason = 3; }
     }
 }
@@ -407,7 +412,7 @@ __device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const fl
             if (base + i < n) st_dev(&cdf[base + i], excl + v[i]);
         if (threadIdx.x == 0) st_dev(&tile_sum[bid], tot);
     }
-    if (!last_block_done(&ctl->ticket[1], nblocks)) return false;
+    if (!last_block_done(&ctl->ticket[1][0], nblocks)) return false;
     if (threadIdx.x < 64) {                               // exclusive tile offsets: wave scan, 64 tiles a pass
         const int lane = threadIdx.x;
         double carry = 0.0;
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
     __shared__ int32_t pick[3];
     if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u, tol, blockIdx.x, gridDim.x, pick)) return;
     if (threadIdx.x == 0) {
-        ctl->ticket[1] = 0;
+        ctl->ticket[1][0] = 0;
         if (!pick[0] || !pick[2]) { ctl->abort_iter = iter; ctl->abort_reason = 2; return; }
         centers[next_pos] = pick[1];
         is_center[pick[1]] = 1;
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
     const int parity = lidx & 1;
     const int cur = lidx % 3, next = (lidx + 1) % 3, clear = (lidx + 2) % 3;
     int32_t *fin = parity ? front_b : front_a, *fout = parity ? front_a : front_b;
-    const int32_t cnt = ctl->fcount[cur];
+    const int32_t cnt = ctl->fcount[cur][0];
     const KppState S = state[parity];
     KppState *out = &state[parity ^ 1];
     if (S.mode == 2 || ctl->abort_iter >= 0) {
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
     if (S.mode == 0) {
         if (cnt > 0) {                                                    // one more sweep of this solve
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                ctl->fcount[clear] = 0;
+                ctl->fcount[clear][0] = 0;
                 KppState x = S;
                 x.sw = S.sw + 1; x.launches = S.launches + 1;
                 if (x.sw >= 4094) { ctl->abort_iter = S.t; ctl->abort_reason = 1; x.mode = 2; }   // stamp range
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
             return;
         if (threadIdx.x == 0) {
             ctl->total = total;
-            ctl->ticket[0] = 0;
+            ctl->ticket[0][0] = 0;
             KppState x = S;
             x.mode = 1; x.launches = S.launches + 1;
             if (!(total > 0.0f)) { ctl->abort_iter = S.t; ctl->abort_reason = 3; x.mode = 2; }
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
     if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u_dev[S.t], tol, blockIdx.x, n_tiles, pick))
         return;
     if (threadIdx.x == 0) {
-        ctl->ticket[1] = 0;
+        ctl->ticket[1][0] = 0;
         KppState x = S;
         x.launches = S.launches + 1;
         if (!pick[0] || !pick[2]) {
@@ -565,8 +570,8 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
                 const int32_t src = pick[1];
                 d[src] = 0.0;
                 fout[0] = src;
-                ctl->fcount[next] = 1;
-                ctl->fcount[clear] = 0;
+                ctl->fcount[next][0] = 1;
+                ctl->fcount[clear][0] = 0;
                 x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
             } else {
                 x.mode = 2; x.t = S.t + 1;
@@ -1225,10 +1230,8 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     dp.node_r = dp.node_l + M; dp.level_off = dp.node_r + M; dp.chunk_root = dp.level_off + max_level + 1;
 
     KppCtl h0;
-    h0.abort_iter = -1; h0.abort_reason = 0;
-    h0.fcount[0] = h0.fcount[1] = h0.fcount[2] = 0;
-    h0.ticket[0] = h0.ticket[1] = 0;
-    h0.total = 0.f; h0.maxf = -1.f; h0.n_inf = 0; h0.max_sw = 0;
+    memset(&h0, 0, sizeof(h0));
+    h0.abort_iter = -1; h0.maxf = -1.f;
     GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, sizeof(KppCtl), hipMemcpyHostToDevice, s));
     GEO_HIP_CHECK(hipMemsetAsync(w.mark, 0, (size_t)n * 4, s));
 
@@ -1342,7 +1345,11 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
             if (hc.abort_iter < 0 || hc.abort_reason != 4) break;
             const int32_t t = hc.abort_iter;
             ++handed_back;
-            GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &h0, 7 * sizeof(int32_t), hipMemcpyHostToDevice, s));   // abort, frontier ring, tickets; maxf stays
+            KppCtl hr = hc;                                  // the margin (maxf) of the call stays
+            hr.abort_iter = -1; hr.abort_reason = 0;
+            memset(hr.fcount, 0, sizeof(hr.fcount));
+            memset(hr.ticket, 0, sizeof(hr.ticket));
+            GEO_HIP_CHECK(hipMemcpyAsync(w.ctl, &hr, sizeof(KppCtl), hipMemcpyHostToDevice, s));
             KppState hs;
             if (int rc = run_steps(t, t + 1, &hs, &hc)) return rc;
             if (hc.abort_iter >= 0) break;                 // the step kernel declined too (reasons 1-3): the caller's turn

@@ -77,8 +77,30 @@ def _drop_self(dist: torch.Tensor, idx: torch.Tensor):
     return dist_k.contiguous(), idx_k.contiguous()
 
 
+_TORCH_METRICS = {"manhattan": 1.0, "cityblock": 1.0, "l1": 1.0, "chebyshev": float("inf"), "l2": 2.0, "minkowski": 2.0}
+
+
+def _generic_metric_search(z: torch.Tensor, n_neighbors: int, metric: str):
+    """Metrics without a HIP kernel (sklearn accepts them, knn_graph_optimized.py:40): blockwise torch.cdist + top-k on the
+    GPU, ties by index.  Returns (idx int32, distance f64) including self."""
+    if metric not in _TORCH_METRICS:
+        raise ValueError(f"Metric '{metric}' not valid. Use 'euclidean', 'cosine' or one of {sorted(_TORCH_METRICS)}")
+    N = z.shape[0]
+    zd = z.to(torch.float64)
+    idx_out = torch.empty((N, n_neighbors), dtype=torch.int32, device=z.device)
+    d_out = torch.empty((N, n_neighbors), dtype=torch.float64, device=z.device)
+    step = max(1, min(N, (1 << 27) // max(1, N)))                      # <= 1 GiB of fp64 distances per block
+    for r0 in range(0, N, step):
+        D = torch.cdist(zd[r0:r0 + step], zd, p=_TORCH_METRICS[metric])
+        # stable ranking by (distance, index): sort is stable along the index axis
+        vals, order = torch.sort(D, dim=1, stable=True)
+        idx_out[r0:r0 + step] = order[:, :n_neighbors].to(torch.int32)
+        d_out[r0:r0 + step] = vals[:, :n_neighbors]
+    return idx_out, d_out
+
+
 def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual", group=None,
-                     need_dist: bool = True):
+                     need_dist: bool = True, metric: str = "euclidean"):
     """Resident latents -> (DeviceCSR, distances f64 [N,k'] | None, indices int32 [N,k']); k' = min(k, N-1) >= 1.
     With an initialised process group the query rows are sharded over the ranks (parallel.sharded_knn); a
     connectivity graph with need_dist=False then never gathers the fp64 distances (returned as None)."""
@@ -87,14 +109,26 @@ def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str =
         raise ValueError(f"Invalid symmetry mode: {sym}")
     N = z.shape[0]
     k_eff = max(0, min(k, N - 1))
+    if metric == "cosine":
+        # cosine distance = 1 - <x^, y^> = |x^ - y^|^2 / 2 on the unit rows: the exact fp64-ranked Euclidean search of
+        # csrc/knn.hip on the normalised latents ranks exactly by it (sklearn: cosine_distances, clipped to [0, 2])
+        z64 = z.to(torch.float64)
+        nrm = torch.linalg.vector_norm(z64, dim=1, keepdim=True)
+        z = (z64 / torch.where(nrm == 0, torch.ones_like(nrm), nrm)).to(torch.float32).contiguous()
+    elif metric != "euclidean":
+        idx, dist = _generic_metric_search(z, min(k_eff + 1, N), metric)
+        dist, idx = _drop_self(dist, idx)
+        weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
+        return symmetrize_device(idx, weights, sym), dist, idx
     idx, d2 = sharded_knn(z, min(k_eff + 1, N), knn_search_device, group,
-                          gather_d2=need_dist or mode == "distance")
+                          gather_d2=need_dist or mode == "distance" or metric == "cosine")
     if callable(d2):                  # multi-rank connectivity graph: distances only if a self match is displaced
         me = torch.arange(N, device=idx.device, dtype=idx.dtype)
         if bool((idx[:, 0] == me).all()):          # same gathered idx on every rank -> same decision on every rank
             return symmetrize_device(idx[:, 1:].contiguous(), None, sym), None, idx[:, 1:].contiguous()
         d2 = d2()
-    dist, idx = _drop_self(torch.sqrt(d2), idx)
+    dist = torch.clamp(d2 * 0.5, 0.0, 2.0) if metric == "cosine" else torch.sqrt(d2)
+    dist, idx = _drop_self(dist, idx)
     weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
     return symmetrize_device(idx, weights, sym), dist, idx
 
@@ -191,13 +225,11 @@ def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean
                 {"distances": np.empty((0, 0), np.float32), "indices": np.empty((0, 0), dtype=int)})
     if max(0, min(k, N - 1)) == 0:
         return _empty_result(N)
-    if metric != "euclidean":
-        raise ValueError(f"metric '{metric}' is not supported by the HIP k-NN kernel (euclidean only)")
     if sym not in _SYM_MODE:
         raise ValueError(f"Invalid symmetry mode: {sym}")
     dev = device()
     z_dev = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).to(dev)
-    G, dist, idx = knn_graph_device(z_dev, k, mode=mode, sym=sym)
+    G, dist, idx = knn_graph_device(z_dev, k, mode=mode, sym=sym, metric=metric)
     info = {"distances": dist.to(torch.float32).cpu().numpy(), "indices": idx.cpu().numpy().astype(np.int64)}
     return G.to_scipy(), info
 
