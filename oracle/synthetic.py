@@ -56,3 +56,27 @@ def zero_clusters(sizes, w: float = 1.0):
 
 
 ZERO_CASES = (((4, 3), 5, 0), ((4, 3), 6, 42), ((6,), 4, 1), ((3, 3, 3), 8, 7), ((5, 1, 4), 7, 3))
+
+
+def seeded_state_dict(template, seed: int):
+    """A state dict with the template's keys / shapes / dtypes filled from numpy's RandomState in sorted key order:
+    weights uniform in +-1/sqrt(fan_in), norm scales in [0.5, 1.5], running variances in [0.5, 1.5], counters 0 --
+    the same values wherever it is regenerated (fixtures store outputs, never weights)."""
+    import torch
+    r = np.random.RandomState(seed)
+    out = {}
+    for key in sorted(template.keys()):
+        t = template[key]
+        shape = tuple(t.shape)
+        if not t.dtype.is_floating_point:
+            out[key] = torch.zeros(shape, dtype=t.dtype)
+            continue
+        if key.endswith("running_var") or (key.endswith(".weight") and len(shape) == 1):
+            v = r.uniform(0.5, 1.5, size=shape)
+        elif key.endswith("running_mean") or key.endswith(".bias"):
+            v = r.uniform(-0.2, 0.2, size=shape)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else max(1, shape[0])
+            v = r.uniform(-1.0, 1.0, size=shape) / np.sqrt(max(1, fan_in))
+        out[key] = torch.from_numpy(np.asarray(v, dtype=np.float32)).to(t.dtype)
+    return out

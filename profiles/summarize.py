@@ -41,11 +41,14 @@ def pmc_summary(sub, counter):
 fetch, f_out = pmc_summary("pmc_fetch", "FETCH_SIZE")
 write, w_out = pmc_summary("pmc_write", "WRITE_SIZE")
 pick = lambda per, name: sorted(next(v for k, v in per.items() if name in k))
-sw_f, sw_w = pick(fetch, "sweep_chunk16_kernel"), pick(write, "sweep_chunk16_kernel")
-cm = pick(fetch, "colmin_kernel")
 bench = last_json(os.path.join(src, "pmc_fetch.json"))
+kernel = bench["roofline"]["kernel"]                             # the sweep kernel this build's bench ran
+sw_f, sw_w = pick(fetch, kernel), pick(write, kernel)
+fixed_point = kernel == "sweep_chunk32u_kernel"
+cal_kernel = "colmin32_kernel" if fixed_point else "colmin_kernel"
+cm = pick(fetch, cal_kernel)
 g = bench["config"]["graph"]
-known = g["nodes"] * 512 * 8.0                                   # colmin reads the K x N fp64 rows once
+known = g["nodes"] * 512 * (4.0 if fixed_point else 8.0)          # colmin reads the K x N distance rows once
 raw = cm[-1][1] * 1024.0
 fetch_raw = sum(x for _, x in sw_f) * 1024.0 / len(sw_f)
 wr = sum(x for _, x in sw_w) * 1024.0 / len(sw_w)
@@ -54,11 +57,11 @@ traffic = {
               f"--warmup 0 --no-cpu-baseline, workload c2, MI355X ({tag}; profiles/collect.sh)",
     "units": "FETCH_SIZE/WRITE_SIZE are reported in KiB; gfx950 FETCH_SIZE counts half of the bytes of coalesced row "
              "reads (MI355X_MICROARCH.md, HBM section)",
-    "calibration": {"kernel": "colmin_kernel", "known_read_bytes": known, "fetch_size_bytes_raw": raw,
+    "calibration": {"kernel": cal_kernel, "known_read_bytes": known, "fetch_size_bytes_raw": raw,
                     "ratio_known_over_raw": known / raw},
-    "kernel": "sweep_chunk16_kernel", "launches": len(sw_f),
-    "fetch_size_bytes_raw_per_launch": fetch_raw, "fetch_bytes_corrected_per_launch": 2.0 * fetch_raw,
-    "write_bytes_per_launch": wr, "hbm_bytes_per_launch": 2.0 * fetch_raw + wr,
+    "kernel": kernel, "tag": tag, "launches": len(sw_f),
+    "fetch_size_bytes_raw_per_launch": fetch_raw, "fetch_bytes_corrected_per_launch": (known / raw) * fetch_raw,
+    "write_bytes_per_launch": wr, "hbm_bytes_per_launch": (known / raw) * fetch_raw + wr,
     "per_launch_fetch_KiB": [round(x) for _, x in sw_f],
     "note": "L2-side (fabric) requests: Infinity-Cache hits are included, so this is an upper bound of HBM traffic. "
             f"Algorithmic bytes per launch are {bench['roofline']['algorithmic_bytes_per_launch']:.3e}.",

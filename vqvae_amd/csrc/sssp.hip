@@ -359,22 +359,41 @@ __device__ __forceinline__ void relax_edge32u(const uint32_t *__restrict__ D, un
     best = cand < best ? cand : best;
 }
 
-// rows sorted by decreasing number of 16-entry chunks (counting sort: histogram, offsets, scatter)
-__global__ __launch_bounds__(256) void row_hist_kernel(const int32_t *__restrict__ chunk_cnt, int32_t n, int32_t *__restrict__ hist) {
-    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-        const int32_t c = chunk_cnt[v] < 255 ? chunk_cnt[v] : 255;
-        atomicAdd(&hist[255 - c], 1);                        // bin 0 = longest rows
-    }
-}
-__global__ void row_offsets_kernel(int32_t *hist) {       // one thread: 256 bins -> exclusive offsets, in place
-    int32_t run = 0;
-    for (int b = 0; b < 256; ++b) { const int32_t c = hist[b]; hist[b] = run; run += c; }
-}
-__global__ __launch_bounds__(256) void row_scatter_kernel(const int32_t *__restrict__ chunk_cnt, int32_t n, int32_t *cursor,
-                                                         int32_t *__restrict__ row_order) {
-    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-        const int32_t c = chunk_cnt[v] < 255 ? chunk_cnt[v] : 255;
-        row_order[atomicAdd(&cursor[255 - c], 1)] = v;
+// rows sorted by decreasing number of 16-entry chunks: counting sort in ONE workgroup (histogram and cursors in LDS; the
+// lanes of a wave that fall into the same bin -- most rows have 2 or 3 chunks -- share one LDS atomic)
+__global__ __launch_bounds__(1024) void row_order_kernel(const int32_t *__restrict__ chunk_cnt, int32_t n,
+                                                        int32_t *__restrict__ row_order) {
+    __shared__ int32_t hist[256];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int32_t v0 = 0; v0 < n; v0 += 1024) {
+            const int32_t v = v0 + threadIdx.x;
+            const bool live = v < n;
+            int bin = -1;
+            if (live) { const int32_t c = chunk_cnt[v]; bin = 255 - (c < 255 ? c : 255); }      // bin 0 = longest rows
+            unsigned long long todo = __ballot(live);
+            while (todo) {                                                   // one LDS atomic per distinct bin of the wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const int b = __builtin_amdgcn_readlane(bin, leader);
+                const unsigned long long same = __ballot(live && bin == b);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&hist[b], __popcll(same));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (pass == 1 && live && bin == b) row_order[base + __popcll(same & lane_lt)] = v;
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x == 0) {                                           // counts -> exclusive offsets (the pass-1 cursors)
+                int32_t run = 0;
+                for (int b = 0; b < 256; ++b) { const int32_t c = hist[b]; hist[b] = run; run += c; }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -884,10 +903,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
             const double unit = std::ldexp(1.0, -shift);
             uint32_t *dist32 = reinterpret_cast<uint32_t *>(w.dist);
             weight_units_kernel<<<geo::grid_for(nnz, 256, 2048), 256, 0, stream>>>(weights, nnz, shift, wunits);
-            GEO_HIP_CHECK(hipMemsetAsync(row_hist, 0, 256 * sizeof(int32_t), stream));
-            row_hist_kernel<<<geo::grid_for(n, 256, 256), 256, 0, stream>>>(chunk_cnt, n, row_hist);
-            row_offsets_kernel<<<1, 1, 0, stream>>>(row_hist);
-            row_scatter_kernel<<<geo::grid_for(n, 256, 256), 256, 0, stream>>>(chunk_cnt, n, row_hist, row_order);
+            row_order_kernel<<<1, 1024, 0, stream>>>(chunk_cnt, n, row_order);
             GEO_LAUNCH_CHECK();
             std::vector<int32_t> hsrc32((size_t)nb32 * 32, -1), hrow32((size_t)nb32 * 32, -1), hf(nb32), hc(2 * (size_t)nb32);
             for (int32_t i = 0; i < n_sources; ++i) { hsrc32[i] = host_sources[i]; hrow32[i] = i; }
