@@ -201,6 +201,12 @@ typedef struct geo_decoder_desc {
     const float *w2, *b2;                  /* deconv_layers.3 weight [c1][c2][4][4], bias [c2] */
     const float *g2, *be2, *rm2, *rv2;     /* deconv_layers.4 */
     const float *w3, *b3;                  /* deconv_layers.6 weight [c2][out_channels][4][4], bias */
+    /* train-mode BatchNorm also folds every batch into its running statistics (torch: momentum 0.1), once per decoder
+     * call of riemannian_metric.py:57-58, i.e. per (chunk, start | end side) in order.  update_running != 0 (with
+     * norm == 1, bn_train != 0 and the four rm / rv pointers non-null) does the same IN PLACE on rm1, rv1, rm2, rv2
+     * (unbiased batch variance); num_batches_tracked (+2 per chunk) is the caller's to advance. */
+    int32_t update_running;
+    float momentum;
 } geo_decoder_desc;
 
 size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size);

@@ -165,3 +165,27 @@ def test_groupnorm_decoder_outside_the_kernels_takes_the_autograd_path():
     L64 = om.edge_lengths(sd, "group", 28, zs[:512], ze[:512], batch_size=512, training=False, dtype=torch.float64).numpy()
     rel = np.abs(L.cpu().numpy() - L64) / L64
     assert L.is_cuda and np.mean(rel <= 1e-4) >= 0.99
+
+
+@pytest.mark.parametrize("bs", [512, 100])
+def test_train_mode_jvp_updates_batchnorm_running_statistics(golden, bs):
+    """torch folds every train-mode batch into running_mean / running_var (momentum 0.1, unbiased variance) and counts
+    it; the reference's edge_lengths_riemannian therefore mutates the decoder (riemannian_metric.py:57-58).  The HIP
+    path does the same, in call order (start side, end side of each chunk): values from the reference run."""
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    g = golden("bn_running_stats")
+    for where in ("cuda", "cpu"):                       # resident decoder (updated in place) and a CPU one (copied back)
+        dec, sd, zs, ze, _ = _decoder("fm_batch", True)
+        dec = dec.to(where)
+        edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs)
+        st = dec.state_dict()
+        for idx in (1, 4):
+            for key in ("running_mean", "running_var"):
+                ref = g[f"bs{bs}/deconv_layers.{idx}.{key}"]
+                np.testing.assert_allclose(st[f"deconv_layers.{idx}.{key}"].cpu().numpy(), ref, rtol=2e-5, atol=1e-6)
+            assert int(st[f"deconv_layers.{idx}.num_batches_tracked"]) == int(g[f"bs{bs}/deconv_layers.{idx}.num_batches_tracked"])
+    dec, sd, zs, ze, _ = _decoder("fm_batch", False)    # eval mode: untouched
+    dec = dec.cuda()
+    before = {k: v.clone() for k, v in dec.state_dict().items()}
+    edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs)
+    assert all(torch.equal(v, dec.state_dict()[k]) for k, v in before.items())

@@ -19,7 +19,8 @@ class DecoderDesc(ctypes.Structure):
                                     "bn_train", "groups1", "groups2")]
                 + [("eps", ctypes.c_float)]
                 + [(n, c_p) for n in ("w_in", "b_in", "w1", "b1", "g1", "be1", "rm1", "rv1",
-                                      "w2", "b2", "g2", "be2", "rm2", "rv2", "w3", "b3")])
+                                      "w2", "b2", "g2", "be2", "rm2", "rv2", "w3", "b3")]
+                + [("update_running", i32), ("momentum", ctypes.c_float)])
 
 
 _SIGNATURES = {

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__res
                                                             int npx, int C, int64_t e_base, int64_t n_edges,
                                                             int batch, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps,
-                                                            NormConst *__restrict__ consts, int n_groups) {
+                                                            NormConst *__restrict__ consts, int n_groups,
+                                                            float2 *__restrict__ stats_out) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_groups * C; i += gridDim.x * blockDim.x) {
         const int g = i / C, c = i % C;
         const int chunk = g >> 1;
@@ -199,11 +200,33 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__res
             const double mxt = (sxt - mu * st) * inv / n;      // mean(xhat * t)
             k.mu = (float)mu; k.sc = (float)(inv * gamma[c]); k.beta = beta[c];
             k.mt = (float)mt; k.c5 = (float)(inv * mxt);
+            // batch mean and UNBIASED variance, what torch folds into running_mean / running_var (n = 1: no update)
+            if (stats_out) stats_out[i] = make_float2((float)mu, n > 1 ? (float)(var * n / (n - 1.0)) : -1.0f);
         } else {
             k.mu = 0; k.sc = 0; k.beta = 0; k.mt = 0; k.c5 = 0;
+            if (stats_out) stats_out[i] = make_float2(0.f, -1.0f);
         }
         consts[i] = k;
     }
+}
+
+// BatchNorm2d in training mode also folds every batch into its running statistics (momentum m):
+//   running = (1 - m) * running + m * batch_stat, once per forward call, i.e. per (chunk, endpoint side) group IN ORDER
+// (riemannian_metric.py:57-58 calls the decoder for the start side, then the end side of each chunk).  One thread per
+// channel walks the groups of a pass sequentially.
+__global__ __launch_bounds__(256) void running_update_kernel(const float2 *__restrict__ stats, int n_groups, int C, float m,
+                                                            float *__restrict__ running_mean, float *__restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < n_groups; ++g) {
+        const float2 st = stats[(size_t)g * C + c];
+        if (st.y < 0.f) continue;                          // empty or single-element batch
+        rm = (1.0f - m) * rm + m * st.x;
+        rv = (1.0f - m) * rv + m * st.y;
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
 }
 
 // mode 0 (none) / running statistics: one row of constants shared by every group.
@@ -957,6 +980,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
     b += geo::align_up(tiles * s.n1 * 4 * 8) + geo::align_up(tiles * s.n2 * 4 * 8);         // partial sums
     b += geo::align_up((groups + 1) * s.c1 * sizeof(NormConst)) + geo::align_up((groups + 1) * s.c2 * sizeof(NormConst));
+    b += geo::align_up((groups + 1) * (size_t)(s.c1 > s.c2 ? s.c1 : s.c2) * sizeof(float2));      // batch statistics
     b += geo::align_up(slots * 4) * 2;                                                      // norms, slot_valid
     if (dc->norm == 2) b += 2 * geo::align_up(slots * 32 * sizeof(float4));                 // GroupNorm statistics
     p->bytes = b + 4096;
@@ -998,6 +1022,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     double *part1 = ar.take<double>(tiles * s.n1 * 4), *part2 = ar.take<double>(tiles * s.n2 * 4);
     NormConst *k1 = ar.take<NormConst>((groups + 1) * s.c1), *k2 = ar.take<NormConst>((groups + 1) * s.c2);
     float *norms = ar.take<float>(slots);
+    float2 *stats = ar.take<float2>((groups + 1) * (size_t)(s.c1 > s.c2 ? s.c1 : s.c2));
     int32_t *slot_valid = ar.take<int32_t>(slots);
     float4 *gs1 = nullptr, *gs2 = nullptr;
     if (dc->norm == 2) {
@@ -1041,6 +1066,8 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                     dc->groups1, dc->groups2, s.c2);
     }
     const bool batch_stats = dc->norm == 1 && dc->bn_train;
+    // train-mode BatchNorm with tracked statistics: the batches are folded into running_mean / running_var in call order
+    const bool track = batch_stats && dc->update_running && dc->rm1 && dc->rv1 && dc->rm2 && dc->rv2;
     if (!batch_stats) {
         finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c1, dc->norm, dc->g1, dc->be1, dc->rm1, dc->rv1, dc->eps, k1);
         GEO_LAUNCH_CHECK();
@@ -1069,7 +1096,11 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
             finalize_batch_kernel<<<geo::grid_for(p_groups * s.c1, 256), 256, 0, stream>>>(
-                part1, pl.tiles_per_group, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups);
+                part1, pl.tiles_per_group, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups,
+                track ? stats : nullptr);
+            if (track)
+                running_update_kernel<<<(s.c1 + 255) / 256, 256, 0, stream>>>(stats, (int)p_groups, s.c1, dc->momentum,
+                                                                          const_cast<float *>(dc->rm1), const_cast<float *>(dc->rv1));
             GEO_LAUNCH_CHECK();
         }
         if (gs1) {
@@ -1116,7 +1147,11 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
             finalize_batch_kernel<<<geo::grid_for(p_groups * s.c2, 256), 256, 0, stream>>>(
-                part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups);
+                part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups,
+                track ? stats : nullptr);
+            if (track)
+                running_update_kernel<<<(s.c2 + 255) / 256, 256, 0, stream>>>(stats, (int)p_groups, s.c2, dc->momentum,
+                                                                          const_cast<float *>(dc->rm2), const_cast<float *>(dc->rv2));
             GEO_LAUNCH_CHECK();
         }
         if (gs2) {

@@ -38,6 +38,7 @@ def edge_lengths_device(export: DecoderExport, z_start: torch.Tensor, z_end: tor
     with torch.cuda.device(dev):
         _lib.check(lib.geo_decoder_jvp_pairs(export.desc, ptr(z_start), ptr(z_end), E, int(batch_size), ptr(out),
                                              ptr(ws), ws.numel(), stream_ptr()), "geo_decoder_jvp_pairs")
+    export.commit_running_stats(2 * ((E + int(batch_size) - 1) // int(batch_size)))
     return out
 
 
@@ -57,6 +58,7 @@ def edge_lengths_graph_device(export: DecoderExport, z: torch.Tensor, src: torch
     with torch.cuda.device(dev):
         _lib.check(lib.geo_decoder_jvp_edges(export.desc, ptr(z), z.shape[0], ptr(src), ptr(dst), E, int(batch_size),
                                              ptr(out), ptr(ws), ws.numel(), stream_ptr()), "geo_decoder_jvp_edges")
+    export.commit_running_stats(2 * ((E + int(batch_size) - 1) // int(batch_size)))
     return out
 
 

@@ -145,6 +145,28 @@ class DecoderExport:
                     self.tensors["be" + t] = torch.zeros(c, device=dev)
         else:
             d.norm, d.eps, d.bn_train = 0, 1e-5, 0
+        # train-mode BatchNorm with tracked statistics: the kernels fold every batch into running_mean / running_var
+        # as torch does (riemannian_metric.py:57-58 runs the decoder in whatever mode it is in); a cumulative average
+        # (momentum=None) is not reproduced
+        self._bn_layers = [seq[1], seq[4]] if isinstance(norm, nn.BatchNorm2d) else []
+        self.tracks_running = bool(d.bn_train and self._bn_layers and norm.running_mean is not None
+                                   and norm.momentum is not None)
+        d.update_running = 1 if self.tracks_running else 0
+        d.momentum = float(norm.momentum) if self.tracks_running else 0.0
         for name, t in self.tensors.items():
             setattr(d, name, None if t is None else ctypes.c_void_p(t.data_ptr()))
         self.desc = d
+
+    def commit_running_stats(self, n_calls: int) -> None:
+        """After a JVP run over `n_calls` decoder calls (2 per chunk): write the updated statistics back when the export
+        holds copies (decoder on another device / dtype) and advance num_batches_tracked."""
+        if not self.tracks_running:
+            return
+        with torch.no_grad():
+            for tag, layer in zip(("1", "2"), self._bn_layers):
+                for attr, key in (("running_mean", "rm" + tag), ("running_var", "rv" + tag)):
+                    buf, mine = getattr(layer, attr), self.tensors[key]
+                    if buf.data_ptr() != mine.data_ptr():
+                        buf.copy_(mine.to(buf.device, buf.dtype))
+                if layer.num_batches_tracked is not None:
+                    layer.num_batches_tracked += n_calls
