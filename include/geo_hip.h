@@ -116,8 +116,11 @@ int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *we
  * query rows [row0,row1) of z, ranked on fp64 squared distances, ties ordered by index.
  * form = 1: |x|^2 - 2 x.y + |y|^2 clamped at 0 (sklearn brute force, d > 15); form = 0: sum of squared
  * differences (sklearn kd-tree, d <= 15).  idx_out i32 [rows][n_neighbors], d2_out f64 likewise,
- * both sorted ascending.  n_neighbors <= 64, d <= 128.
+ * both sorted ascending.  n_neighbors <= GEO_KNN_MAX_NEIGHBORS (lists of up to 64 entries live one
+ * per lane of the query's wave, longer ones two or four per lane; the float32 pre-filter serves
+ * lists <= 64), d <= 128.
  * ------------------------------------------------------------------------------------------ */
+#define GEO_KNN_MAX_NEIGHBORS 256
 size_t geo_knn_workspace_bytes(int64_t n, int32_t d);
 int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neighbors, int32_t form,
                  int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out,

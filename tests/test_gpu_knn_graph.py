@@ -112,6 +112,26 @@ def test_ragged_sizes_vs_oracle():
         np.testing.assert_array_equal(W.data, Wo.data)
 
 
+def test_lists_longer_than_one_wave_vs_oracle():
+    """k + 1 > 64 (two and four list registers per lane): the reference's sklearn search has no such limit
+    (src/geo/knn_graph_optimized.py:40); ties from duplicated rows are ordered by index like the oracle's."""
+    from vqvae_amd.geo.knn_graph_optimized import MAX_NEIGHBORS, build_knn_graph
+    from oracle import knn as okn
+    for N, d, k in ((700, 8, 64), (1500, 16, 99), (900, 33, 127), (1100, 16, 128), (2000, 5, 200), (300, 24, 255)):
+        z = latents(N, d, N + k)
+        z[N // 2:N // 2 + 40] = z[:40]                              # exact ties across the register boundary
+        W, info = build_knn_graph(z, k=k, mode="distance", sym="mutual")
+        Wo, info_o = okn.build_knn_graph(z, k=k, mode="distance", sym="mutual")
+        np.testing.assert_array_equal(info["distances"], info_o["distances"], err_msg=str((N, d, k)))
+        np.testing.assert_array_equal(info["indices"], info_o["indices"], err_msg=str((N, d, k)))
+        np.testing.assert_array_equal(W.indices, Wo.indices)
+        np.testing.assert_array_equal(W.data, Wo.data)
+        np.testing.assert_array_equal(W.indptr, Wo.indptr)
+    assert MAX_NEIGHBORS == 256
+    with pytest.raises(ValueError):
+        build_knn_graph(latents(400, 8, 1), k=MAX_NEIGHBORS)
+
+
 def _oracle_rows(z, n_neighbors, form, r0, r1):
     import ctypes
     from oracle import _clib

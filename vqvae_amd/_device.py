@@ -44,8 +44,12 @@ def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
     return buf
 
 
-def release_workspace() -> None:
-    _ws_cache.clear()
+def release_workspace(above_bytes: int = 0) -> None:
+    """Hand scratch buffers larger than `above_bytes` back to torch's caching allocator (stream ordered: kernels
+    already queued on the current stream keep their memory).  The JVP stage's tens of GB then serve later
+    allocations instead of sitting idle behind the much smaller graph and SSSP workspaces."""
+    for key in [k for k, b in _ws_cache.items() if b.numel() > above_bytes]:
+        del _ws_cache[key]
 
 
 @dataclass

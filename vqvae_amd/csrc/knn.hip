@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     }
 }
 
-template <int DCH, int Q, bool EXPANSION>
+template <int DCH, int Q, bool EXPANSION, int LR = 1>
 __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32, const double *__restrict__ zq64,
                                                  const double *__restrict__ nrm, const double *__restrict__ nrm_q,
                                                  int64_t n, int nch, int kq, int64_t row0, int64_t row1,
@@ -57,11 +57,18 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
     if (q0 >= row1) return;
     const int dp = nch * DCH;
 
-    double lv[Q];      // lane i: i-th smallest squared distance seen so far for query q
-    int32_t li[Q];     //         and its corpus index
+    // list position p = 64 r + lane holds the p-th smallest squared distance seen so far for query q (LR registers
+    // per lane: lists of up to 64 LR entries) and its corpus index
+    double lv[Q][LR];
+    int32_t li[Q][LR];
     double tau[Q];     // wave-uniform: current kq-th smallest
+    const int tau_reg = (kq - 1) >> 6, tau_lane = (kq - 1) & 63;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { lv[q] = inf64(); li[q] = -1; tau[q] = inf64(); }
+    for (int q = 0; q < Q; ++q) {
+        tau[q] = inf64();
+#pragma unroll
+        for (int r = 0; r < LR; ++r) { lv[q][r] = inf64(); li[q][r] = -1; }
+    }
 
     for (int64_t c0 = 0; c0 < n; c0 += 64) {
         const int64_t j = c0 + lane;
@@ -113,21 +120,38 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
                 if (!(val < tau[q])) continue;             // tau shrank since the ballot
                 const int32_t id = (int32_t)(c0 + src_lane);
                 // stable insertion behind equal keys: candidates arrive in ascending index order
-                const int pos = __builtin_popcountll(__ballot(lv[q] <= val));
-                const double up_v = __shfl_up(lv[q], 1, 64);
-                const int32_t up_i = __shfl_up(li[q], 1, 64);
-                if (lane > pos) { lv[q] = up_v; li[q] = up_i; }
-                if (lane == pos) { lv[q] = val; li[q] = id; }
-                tau[q] = readlane_f64(lv[q], kq - 1);
+                int pos = 0;
+#pragma unroll
+                for (int r = 0; r < LR; ++r) pos += __builtin_popcountll(__ballot(lv[q][r] <= val));
+#pragma unroll
+                for (int r = LR - 1; r >= 0; --r) {            // top register first: it takes lane 63 of the one below
+                    double up_v = __shfl_up(lv[q][r], 1, 64);
+                    int32_t up_i = __shfl_up(li[q][r], 1, 64);
+                    if (r > 0) {
+                        const double carry_v = readlane_f64(lv[q][r - 1], 63);
+                        const int32_t carry_i = __builtin_amdgcn_readlane(li[q][r - 1], 63);
+                        if (lane == 0) { up_v = carry_v; up_i = carry_i; }
+                    }
+                    const int g = 64 * r + lane;
+                    if (g > pos) { lv[q][r] = up_v; li[q][r] = up_i; }
+                    if (g == pos) { lv[q][r] = val; li[q][r] = id; }
+                }
+#pragma unroll
+                for (int r = 0; r < LR; ++r)
+                    if (r == tau_reg) tau[q] = readlane_f64(lv[q][r], tau_lane);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int64_t qr = q0 + q;
-        if (qr < row1 && lane < kq) {
-            idx_out[(qr - row0) * kq + lane] = li[q];
-            d2_out[(qr - row0) * kq + lane] = lv[q];
+#pragma unroll
+        for (int r = 0; r < LR; ++r) {
+            const int g = 64 * r + lane;
+            if (qr < row1 && g < kq) {
+                idx_out[(qr - row0) * kq + g] = li[q][r];
+                d2_out[(qr - row0) * kq + g] = lv[q][r];
+            }
         }
     }
 }
@@ -389,21 +413,27 @@ KnnPlan plan_for(int d) {
     return p;
 }
 
-template <int DCH, int Q>
+template <int DCH, int Q, int LR = 1>
 int launch_knn(bool expansion, const float *zp32, const double *zq64, const double *nrm, const double *nrm_q, int64_t n,
                int nch, int kq, int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out, hipStream_t s) {
     const int64_t rows = row1 - row0;
     const int64_t waves = (rows + Q - 1) / Q;
     const unsigned grid = (unsigned)((waves + KNN_WAVES - 1) / KNN_WAVES);
     if (expansion)
-        knn_kernel<DCH, Q, true><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
+        knn_kernel<DCH, Q, true, LR><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
     else
-        knn_kernel<DCH, Q, false><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
+        knn_kernel<DCH, Q, false, LR><<<grid, 256, 0, s>>>(zp32, zq64, nrm, nrm_q, n, nch, kq, row0, row1, idx_out, d2_out);
     GEO_LAUNCH_CHECK();
     return GEO_OK;
 }
 
-
+// lists longer than one wave (64 < kq <= 256): 2 or 4 list registers per lane, 4 queries per wave
+template <int DCH>
+int launch_knn_wide(bool expansion, const float *zp32, const double *zq64, const double *nrm, int64_t n, int nch, int kq,
+                    int64_t row0, int64_t row1, int32_t *idx_out, double *d2_out, hipStream_t s) {
+    if (kq <= 128) return launch_knn<DCH, 4, 2>(expansion, zp32, zq64, nrm, nrm, n, nch, kq, row0, row1, idx_out, d2_out, s);
+    return launch_knn<DCH, 4, 4>(expansion, zp32, zq64, nrm, nrm, n, nch, kq, row0, row1, idx_out, d2_out, s);
+}
 
 bool filter_applies(int64_t n, int dp) {
     if (geo::options().knn_filter == 0) return false;
@@ -434,8 +464,8 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
     GEO_REQUIRE(z && idx_out && d2_out && ws, "geo_knn_topk: null pointer");
     GEO_REQUIRE(n > 0 && n < (int64_t)1 << 31, "geo_knn_topk: n=%lld out of range", (long long)n);
     GEO_REQUIRE(d > 0 && d <= 128, "geo_knn_topk: d=%d not in [1,128]", d);
-    GEO_REQUIRE(n_neighbors > 0 && n_neighbors <= 64 && n_neighbors <= n,
-                "geo_knn_topk: n_neighbors=%d not in [1, min(64, n)]", n_neighbors);
+    GEO_REQUIRE(n_neighbors > 0 && n_neighbors <= GEO_KNN_MAX_NEIGHBORS && n_neighbors <= n,
+                "geo_knn_topk: n_neighbors=%d not in [1, min(%d, n)]", n_neighbors, GEO_KNN_MAX_NEIGHBORS);
     GEO_REQUIRE(0 <= row0 && row0 <= row1 && row1 <= n, "geo_knn_topk: bad row range");
     if (row0 == row1) return GEO_OK;
     const KnnPlan p = plan_for(d);
@@ -451,6 +481,11 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
     GEO_LAUNCH_CHECK();
     const bool ex = form != 0;
     const int64_t rows = row1 - row0;
+    if (n_neighbors > 64) {                       // no float32 filter here: its candidate lists are sized for kq <= 64
+        if (p.dch == 8) return launch_knn_wide<8>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        if (p.dch == 16) return launch_knn_wide<16>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+        return launch_knn_wide<32>(ex, zp32, zq64, nrm, n, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
+    }
     if (filter_applies(n, p.dp) && (n + FILTER_STRIDE - 1) / FILTER_STRIDE >= n_neighbors) {
         const int64_t m = (n + FILTER_STRIDE - 1) / FILTER_STRIDE;
         float *zs32 = ar.take<float>((size_t)m * p.dp);

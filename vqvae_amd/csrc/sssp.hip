@@ -826,7 +826,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     float *lm_key = nullptr;
     int32_t *lm_flags = nullptr;
     uint32_t *wunits = nullptr, *wrange = nullptr;           // 32-bit fixed-point weights / their range
-    int32_t *chunk_cnt = nullptr, *row_order = nullptr, *row_hist = nullptr;
+    int32_t *chunk_cnt = nullptr, *row_order = nullptr;
     const geo::Options &opt = geo::options();
     const int act_mode = opt.sssp_act;
     // sparse body while fewer than n/sparse_div rows moved in the previous sweep; map kept below n/map_div
@@ -841,7 +841,7 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
         int32_t *ccnt = ar.take<int32_t>((size_t)n + 1), *coff = ar.take<int32_t>((size_t)n + 1);
         chunk_cnt = ccnt;
         row_order = ar.take<int32_t>((size_t)n);
-        row_hist = ar.take<int32_t>(256);
+        (void)ar.take<int32_t>(256);                          // (layout kept in step with geo_sssp_workspace_bytes)
         const size_t max_chunks = (size_t)n + (size_t)(nnz / 16) + 16;
         chunk_node = ar.take<int32_t>(max_chunks);
         chunk_start = ar.take<int32_t>(max_chunks);

@@ -18,7 +18,7 @@ from .. import _lib
 from .._device import DeviceCSR, device, ptr, stream_ptr, workspace
 
 _SYM_MODE = {"union": 0, "mutual": 1}
-MAX_NEIGHBORS = 64          # n_neighbors (k + 1) supported by the wave-resident top-k list
+MAX_NEIGHBORS = 256         # n_neighbors (k + 1) supported by the wave-resident top-k lists (geo_hip.h)
 
 
 # --------------------------------------------------------------------------------- device level
