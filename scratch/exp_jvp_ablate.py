@@ -1,7 +1,7 @@
 """Timing of the JVP stage with a library variant (scratch/abl/libgeo_abl<mask>.so, built with -DGEO_MID_ABLATE=<mask>):
 which part of mid_all_kernel the time goes to.  Results of ablated variants are wrong by construction."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vqvae_amd._lib as _lib
 if len(sys.argv) > 1 and sys.argv[1] != "prod":
     _lib.LIB_PATH = sys.argv[1]

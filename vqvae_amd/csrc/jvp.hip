@@ -521,43 +521,28 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
 // {1,2,5,6} (10 of the 20 (pixel, chunk) products each, 2 or 3 per pixel): 4 x 2 accumulator tiles = 128
 // registers per wave, so two waves share a SIMD and one's weight-fragment loads (L2) hide behind the other's
 // MFMAs.
-//
-// HALF = true: the two wave groups are two independent 256-thread workgroups (blocks b and b + 8: same XCD,
-// so the second read of the tile's pre-activations is an L2 hit), each staging the A blocks itself into a
-// single LDS buffer (52 KB: two workgroups per CU).  The staging is done twice per tile, but the two
-// workgroups of a CU are never in the same phase: one's staging, barriers, first weight-fragment round trip
-// and epilogue stores run under the other's MFMAs, which one 512-thread workgroup per CU cannot do.
-template <int C1, bool GN, bool HALF>
-__global__ __launch_bounds__(HALF ? 256 : 512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+template <int C1, bool GN>
+__global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
                                                         const NormConst *__restrict__ consts1, int consts_per_group,
-                                                        int tiles_per_group, int n_tiles, ChunkTable tab, int c2,
+                                                        int tiles_per_group, ChunkTable tab, int c2,
                                                         const unsigned short *__restrict__ B3,
                                                         const float *__restrict__ b2, float *__restrict__ pre2,
                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
                                                         int want_stats, const int32_t *__restrict__ slot_valid,
                                                         const float4 *__restrict__ gs1) {
-    constexpr int NT = HALF ? 256 : 512;
-    constexpr int NBUF = HALF ? 1 : 2;
     constexpr int LDK = C1 + 8;
     constexpr int KS = C1 / 16;
     constexpr int NL = 4;                                      // chunks per wave group
-    constexpr int TPS = NT / TS;                               // staging threads per sample
-    constexpr int CPT = C1 / TPS;                              // channels staged per thread
-    constexpr int GPT = 32 / TPS;                              // GroupNorm groups (of C1/32 channels) per thread
-    __shared__ __attribute__((aligned(16))) unsigned short A3[NBUF][3][2][TS][LDK];   // (double buffered over input pixels)
+    constexpr int CPT = C1 / 16;                               // channels staged per thread
+    __shared__ __attribute__((aligned(16))) unsigned short A3[2][3][2][TS][LDK];   // double buffered over input pixels
     __shared__ NormConst kc[C1];
-    int tile = blockIdx.x, half = 0;
-    if (HALF) {
-        tile = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
-        half = (int)(blockIdx.x >> 3) & 1;
-        if (tile >= n_tiles) return;                           // whole workgroup
-    }
+    const int tile = blockIdx.x;
     const int group = tile / tiles_per_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wq = wave & 3, wg = HALF ? half : wave >> 2;     // column quarter, chunk group
+    const int wq = wave & 3, wg = wave >> 2;                   // column quarter, chunk group
     const int n1 = 4 * C1, n2 = 16 * c2;
     const size_t slot0 = (size_t)tile * TS;
-    for (int c = threadIdx.x; c < C1; c += NT) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
+    for (int c = threadIdx.x; c < C1; c += 512) kc[c] = consts1[(size_t)(consts_per_group ? group : 0) * C1 + c];
 
     f32x16 accp[NL], acct[NL];
 #pragma unroll
@@ -566,33 +551,30 @@ __global__ __launch_bounds__(HALF ? 256 : 512, 2) void mid_all_kernel(const floa
         for (int i = 0; i < 16; ++i) { accp[lc][i] = 0.f; acct[lc][i] = 0.f; }
 
     const int r = lane & 31, h = lane >> 5;
-    // staging: thread -> (sample = tid / TPS, CPT consecutive channels).  The raw pre-activations of the NEXT input
-    // pixel are fetched (HBM) while the MFMAs of the current one run.
-    const int ss = threadIdx.x / TPS, k0 = (threadIdx.x % TPS) * CPT;
+    // staging: thread -> (sample = tid/16, CPT consecutive channels).  The raw pre-activations of the NEXT input
+    // pixel are fetched (HBM) while the MFMAs of the current one run; one barrier per pixel.
+    const int ss = threadIdx.x >> 4, k0 = (threadIdx.x & 15) * CPT;
     float rawp[CPT], rawt[CPT];
     {
         const float *xp = pre1 + (slot0 + ss) * n1 + k0, *xt = tpre1 + (slot0 + ss) * n1 + k0;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
     }
-    // GroupNorm (32 groups): the thread's CPT channels span exactly GPT groups of C1/32 channels
-    float4 gg[GPT];
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) gg[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // GroupNorm (32 groups): the thread's CPT = C1/16 channels span exactly two groups of C1/32 channels
+    float4 gg0 = make_float4(0.f, 0.f, 0.f, 0.f), gg1 = gg0;
     if (GN) {
-#pragma unroll
-        for (int g = 0; g < GPT; ++g) gg[g] = gs1[(slot0 + ss) * 32 + (threadIdx.x % TPS) * GPT + g];
+        gg0 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2];
+        gg1 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2 + 1];
     }
     __syncthreads();                                           // kc visible
     for (int ip = 0; ip < 4; ++ip) {
-        const int buf = HALF ? 0 : ip & 1;
-        if (HALF && ip > 0) __syncthreads();                   // single buffer: every wave is done with the previous pixel
+        const int buf = ip & 1;
         {
             unsigned short pp[3][CPT], pt[3][CPT];
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 float a, ta;
-                if (GN) norm_relu_gn(gg[k / (CPT / GPT)], kc[k0 + k].sc, kc[k0 + k].beta, rawp[k], rawt[k], &a, &ta);
+                if (GN) norm_relu_gn(k < CPT / 2 ? gg0 : gg1, kc[k0 + k].sc, kc[k0 + k].beta, rawp[k], rawt[k], &a, &ta);
                 else norm_relu(kc[k0 + k], rawp[k], rawt[k], &a, &ta);
                 split3(a, pp[0][k], pp[1][k], pp[2][k]);
                 split3(ta, pt[0][k], pt[1][k], pt[2][k]);
@@ -1139,22 +1121,17 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                              mid_opt != 2;
         if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
-    if (mid_half)                                                                                                  \
-        mid_all_kernel<C1V, GNV, true><<<(unsigned)((p_tiles + 7) / 8) * 16, 256, 0, stream>>>(                     \
-            pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_tiles, tab, s.c2, B3, dc->b2, pre2,    \
-            tpre2, part2, batch_stats ? 1 : 0, slot_valid, gs1);                                                   \
-    else                                                                                                           \
-        mid_all_kernel<C1V, GNV, false><<<(unsigned)p_tiles, 512, 0, stream>>>(                                    \
-            pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_tiles, tab, s.c2, B3, dc->b2, pre2,    \
-            tpre2, part2, batch_stats ? 1 : 0, slot_valid, gs1)
-            const bool mid_half = mid_opt != 3;
+    mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
+                                                                    pl.tiles_per_group, tab, s.c2, B3, dc->b2,      \
+                                                                    pre2, tpre2, part2, batch_stats ? 1 : 0,        \
+                                                                    slot_valid, gs1)
             if (gs1) {
-                if (s.c1 == 128) { GEO_MIDA(128, true); }
-                else if (s.c1 == 64) { GEO_MIDA(64, true); }
-                else { GEO_MIDA(32, true); }
-            } else if (s.c1 == 128) { GEO_MIDA(128, false); }
-            else if (s.c1 == 64) { GEO_MIDA(64, false); }
-            else { GEO_MIDA(32, false); }
+                if (s.c1 == 128) GEO_MIDA(128, true);
+                else if (s.c1 == 64) GEO_MIDA(64, true);
+                else GEO_MIDA(32, true);
+            } else if (s.c1 == 128) GEO_MIDA(128, false);
+            else if (s.c1 == 64) GEO_MIDA(64, false);
+            else GEO_MIDA(32, false);
 #undef GEO_MIDA
         } else if (mid_split) {
             if (s.c1 == 128) GEO_MID3(128);
