@@ -46,8 +46,10 @@ def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
 
 def release_workspace(above_bytes: int = 0) -> None:
     """Hand scratch buffers larger than `above_bytes` back to torch's caching allocator (stream ordered: kernels
-    already queued on the current stream keep their memory).  The JVP stage's tens of GB then serve later
-    allocations instead of sitting idle behind the much smaller graph and SSSP workspaces."""
+    already queued on the current stream keep their memory).  The pipeline itself never calls this: the JVP stage's
+    scratch (25 GB at 60 000 x 16, batch 512) stays resident between builds -- measured, handing it back after the
+    stage lets the smaller SSSP workspace split the block and the next build pays a fresh 25 GB allocation (+2.2 ms
+    per 55 ms step).  A caller that builds one codebook and then needs the memory calls it afterwards."""
     for key in [k for k, b in _ws_cache.items() if b.numel() > above_bytes]:
         del _ws_cache[key]
 

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 from scipy import sparse
 
-from .._device import DeviceCSR, device, release_workspace
+from .._device import DeviceCSR, device
 from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
                                        upper_edges_device)
@@ -60,7 +60,6 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
             lambda e0, e1: edge_lengths_graph_device(export, z_flat, src[e0:e1], dst[e0:e1], batch_size), group)
     else:       # e.g. GroupNorm: no kernel, autograd on the GPU (the reference's own method)
         lengths = edge_lengths_riemannian(decoder, z_flat[src.long()], z_flat[dst.long()], batch_size).contiguous()
-    release_workspace(above_bytes=4 << 30)              # the JVP stage's scratch (25 GB at 128k x 16) goes back to the allocator
     t0 = tick("jvp", t0)
 
     W_geo = reweight_device(G, entry_edge, lengths)
