@@ -747,12 +747,17 @@ struct MultiWs {
 // N=60 000, but its per-lane addressing and four CSR rows per wave cost more than the L2 hits return
 // (7-10 TB/s of gathered bytes against 9-19 TB/s).  16 is kept for calls with few sources, where it
 // avoids relaxing padded lanes.
-int choose_sb(int32_t n, int32_t n_sources) {
-    const int forced = geo::options().sssp_sb;               // experiment switch (bench/tests leave it alone)
+int choose_sb(int32_t n, int32_t n_sources, int forced_here) {
+    const int forced = forced_here ? forced_here : geo::options().sssp_sb;   // (option: experiment switch)
     if (forced == 16 || forced == 64) return forced;
     if (n_sources <= 16) return 16;
-    // 16-source batches pay off while one batch (n * 128 bytes) stays within reach of an XCD's 4 MiB L2
-    if (n_sources >= 32 && (size_t)n * 128 <= ((size_t)12 << 20) && (size_t)n * 512 > ((size_t)6 << 20)) return 16;
+    if (n_sources >= 32 && (size_t)n * 512 > ((size_t)6 << 20)) {
+        // 16-source batches pay off while one batch (n * 128 bytes) stays within reach of an XCD's 4 MiB L2 ...
+        if ((size_t)n * 128 <= ((size_t)12 << 20)) return 16;
+        // ... and beyond that as the carrier of the 32-bit fixed-point solve (half the gathered bytes per source:
+        // 145 ms against 414 ms for 1024 sources at N = 1 M); weights that do not qualify come back for 64
+        if (geo::options().sssp_u32 != 0) return 16;
+    }
     return 64;
 }
 
@@ -791,14 +796,14 @@ extern "C" size_t geo_sssp_workspace_bytes(int32_t n, int64_t nnz, int32_t n_sou
     return (multi > single ? multi : single) + 1024;
 }
 
-extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
-                              int64_t nnz, const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
-                              float *dmin_out, int32_t *argmin_out, void *ws, size_t ws_bytes,
-                              int32_t *sweeps_out, void *stream_) {
+static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                           int64_t nnz, const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
+                           float *dmin_out, int32_t *argmin_out, void *ws, size_t ws_bytes,
+                           int32_t *sweeps_out, void *stream_, int force_sb) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     GEO_REQUIRE(n > 0 && n_sources > 0, "geo_sssp_multi: n=%d n_sources=%d must be positive", n, n_sources);
     GEO_REQUIRE(indptr && indices && sources && ws, "geo_sssp_multi: null pointer");
-    const int sb = choose_sb(n, n_sources);
+    const int sb = choose_sb(n, n_sources, force_sb);
     const int32_t nb = (n_sources + sb - 1) / sb;
     const bool chunked = sb == 16 && n_sources > 16;       // 16-edge chunk work items (see sweep_chunk16_kernel)
     GEO_REQUIRE(nnz >= 0, "geo_sssp_multi: nnz must be given");
@@ -992,6 +997,10 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
             }
             g_last_sweep_ms = 0.0;                       // the fp64 solve below is the one that counts
         }
+        // a graph this large took 16-source batches only for the fixed-point solve: the fp64 solve runs 64 per batch
+        if (force_sb == 0 && opt.sssp_sb == 0 && (size_t)n * 128 > ((size_t)12 << 20))
+            return sssp_multi_impl(indptr, indices, weights, n, nnz, sources, n_sources, D_out, P_out, dmin_out,
+                                   argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }
     int32_t total_sweeps = 0;
     bool grouped = false;
@@ -1156,6 +1165,14 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
     }
     GEO_HIP_CHECK(hipStreamSynchronize(stream));
     return GEO_OK;
+}
+
+extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                              int64_t nnz, const int32_t *sources, int32_t n_sources, float *D_out, int32_t *P_out,
+                              float *dmin_out, int32_t *argmin_out, void *ws, size_t ws_bytes,
+                              int32_t *sweeps_out, void *stream_) {
+    return sssp_multi_impl(indptr, indices, weights, n, nnz, sources, n_sources, D_out, P_out, dmin_out, argmin_out, ws,
+                           ws_bytes, sweeps_out, stream_, 0);
 }
 
 extern "C" int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches) {
