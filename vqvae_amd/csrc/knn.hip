@@ -260,20 +260,55 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
     };
     constexpr int EQ_CAP = 128;
     __shared__ unsigned long long eb[4][EQ_CAP];
-    __shared__ int ec[4];
-    if (lane == 0) ec[wave] = 0;
+    int qn = 0;                                                // pairs queued by this wave (wave-uniform)
     auto flush = [&]() {                                       // wave-uniform call
-        const int m = ec[wave] < EQ_CAP ? ec[wave] : EQ_CAP;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int m = qn < EQ_CAP ? qn : EQ_CAP;
         for (int i = lane; i < m; i += 64) {
             const unsigned long long e = eb[wave][i];
             const int64_t row = (int64_t)(e >> 32);
             const int32_t slot = atomicAdd(&cnt[row], 1);
             if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = (int32_t)(e & 0xffffffffu);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) ec[wave] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
+    // Kept pairs go to a per-wave LDS queue first (the returning global atomic that reserves a list slot costs
+    // microseconds, too much inside the MFMA stream; the queue is flushed at tile ends).  The signs of a lane's 32
+    // accumulator entries (two column tiles) are packed into one word; lanes then take their set bits one per round and
+    // get queue positions from the round's ballot: no LDS atomics, a handful of branches per 2 048 pairs.
+    auto keep_pairs = [&](const f32x16v &acc0, const f32x16v &acc1, int64_t cand0) {
+        unsigned any = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) any |= __float_as_uint(acc0[q]) | __float_as_uint(acc1[q]);
+        if (!__ballot((any & 0x80000000u) != 0)) return;       // wave-uniform: nothing to keep in these 2 048 pairs
+        unsigned bits = 0;                                     // bit q: acc0[q] < 0, bit 16 + q: acc1[q] < 0
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            bits |= (__float_as_uint(acc0[q]) >> 31) << q;
+            bits |= (__float_as_uint(acc1[q]) >> 31) << (16 + q);
+        }
+        for (;;) {
+            const unsigned long long hit = __ballot(bits != 0);
+            if (!hit) break;
+            if (bits != 0) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int q = b & 15;
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
+                const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int32_t cand = (int32_t)(cand0 + (b >> 4) * 32 + r);
+                if (pos < EQ_CAP) {
+                    eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
+                } else {                                       // queue full (masses of duplicates): straight to the list
+                    const int32_t slot = atomicAdd(&cnt[row], 1);
+                    if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                }
+            }
+            qn += __builtin_popcountll(hit);
+        }
     };
     fetch(tile_lo);
     put((int)(tile_lo & 1));
@@ -291,34 +326,203 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bs[buf][t][i][lane], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bs[buf][t + 1][i][lane], acc1, 0, 0, 0);
             }
-            unsigned any0 = 0, any1 = 0;                       // sign bits: a negative entry = a pair to keep
+            keep_pairs(acc0, acc1, tile * SCAN_CT + t * 32);       // a negative entry = a pair to keep
+        }
+        if (qn >= EQ_CAP / 2) flush();
+        if (tile + 1 < n_tiles) put(buf ^ 1);
+        __syncthreads();
+    }
+    flush();
+}
+
+// ---- the same filter on the bf16 matrix cores ---------------------------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits.  x_i.x_j ~ hi_i.hi_j + hi_i.lo_j + lo_i.hi_j on
+// v_mfma_f32_32x32x16_bf16 (three 32-cycle instructions per 32 x 32 pairs and 16 dimensions, against DP/2+1 64-cycle
+// float32 ones); the dropped lo.lo term and the parts' own roundings are below 2^-16 |x_i||x_j|, which the caller's eps
+// (relative to |x_i|^2 + |x_j|^2) covers.  The accumulator starts at |x_j|^2 (1 - eps) - u_i, so the sign of the result
+// is the test, as in knn_scan_kernel; the kept pairs take the same queue.
+typedef __bf16 bf16x8k __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// zb [n][2][dpb] bf16 bit patterns: the two parts of every coordinate (dpb = dp rounded up to 16, zero padded)
+__global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ zp32, int64_t n, int dp, int dpb,
+                                                       unsigned short *__restrict__ zb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * dpb; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dpb;
+        const int c = (int)(i % dpb);
+        const float x = c < dp ? zp32[r * dp + c] : 0.0f;
+        const unsigned short hi = bf16_rne(x);
+        const float rest = x - __uint_as_float((unsigned)hi << 16);      // exact
+        zb[(r * 2 + 0) * dpb + c] = hi;
+        zb[(r * 2 + 1) * dpb + c] = bf16_rne(rest);
+    }
+}
+
+template <int DPB, int SCAN_CT>
+__global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short *__restrict__ zb,
+                                                           const double *__restrict__ nrm, const double *__restrict__ u,
+                                                           int64_t n, int64_t row0, int64_t rows, double eps, int splits,
+                                                           int32_t *__restrict__ cnt, int32_t *__restrict__ list) {
+    constexpr int KST = DPB / 16;                              // MFMA k-steps
+    constexpr int ROWB = 2 * DPB * 2 + 16;                     // bytes per candidate in LDS: hi, lo, 16 of padding (banks)
+    __shared__ __attribute__((aligned(16))) unsigned char Ts[2][SCAN_CT * ROWB];
+    __shared__ float Ns[2][SCAN_CT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t qbase = (int64_t)(blockIdx.x / splits) * 128 + wave * 32;   // this wave's 32 queries (local row numbers)
+    const int split = blockIdx.x % splits;                                  // ... against one slice of the corpus
+    // A operand: lane holds A[m = r][k = 16 ks + 8 h .. + 7] = -2 x (both parts: the scaling is exact)
+    bf16x8k ahi[KST], alo[KST];
+    float uq[16];                                              // u of the 16 rows this lane's accumulator entries belong to
+    {
+        const bool live = qbase + r < rows;
+        const int64_t q = live ? qbase + r : rows - 1;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { any0 |= __float_as_uint(acc0[q]); any1 |= __float_as_uint(acc1[q]); }
-            if ((any0 | any1) & 0x80000000u) {
-                // kept pairs go to a per-wave LDS queue first: the returning global atomic that reserves a list slot
-                // costs microseconds, too much inside the MFMA stream; the queue is flushed 64 entries at a time
+        for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int32_t cand = (int32_t)(tile * SCAN_CT + (t + tt) * 32 + r);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        if ((tt ? acc1[q] : acc0[q]) < 0.0f) {
-                            const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
-                            const int pos = atomicAdd(&ec[wave], 1);
-                            if (pos < EQ_CAP) {
-                                eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
-                            } else {                               // queue full (masses of duplicates): straight to the list
-                                const int32_t slot = atomicAdd(&cnt[row], 1);
-                                if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
-                            }
-                        }
-                    }
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float xh = __uint_as_float((unsigned)zb[((row0 + q) * 2 + 0) * DPB + ks * 16 + h * 8 + e] << 16);
+                const float xl = __uint_as_float((unsigned)zb[((row0 + q) * 2 + 1) * DPB + ks * 16 + h * 8 + e] << 16);
+                ahi[ks][e] = (__bf16)(-2.0f * xh);
+                alo[ks][e] = (__bf16)(-2.0f * xl);
             }
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int64_t row = qbase + (qq & 3) + 8 * (qq >> 2) + 4 * h;
+            float ur = -3.0e38f;                               // padded queries keep nothing
+            if (row < rows) {
+                const double ud = u[row];
+                ur = (float)ud;
+                if ((double)ur < ud) ur = nextafterf(ur, 3.4e38f);
+            }
+            uq[qq] = ur;
+        }
+    }
+    const int64_t all_tiles = (n + SCAN_CT - 1) / SCAN_CT, per_split = (all_tiles + splits - 1) / splits;
+    const int64_t tile_lo = per_split * split;
+    const int64_t n_tiles = tile_lo + per_split < all_tiles ? tile_lo + per_split : all_tiles;
+    if (tile_lo >= n_tiles) return;
+    // staging: a candidate's 4 DPB bytes (hi row, lo row) are contiguous in zb; PER 16-byte pieces per thread
+    constexpr int PIECES = SCAN_CT * (4 * DPB / 16);           // 16-byte pieces per tile
+    constexpr int PER = PIECES / 256;
+    static_assert(PIECES % 256 == 0, "tile pieces divide among the threads");
+    unsigned vals[PER][4];
+    float nval = 3.0e38f;
+    auto fetch = [&](int64_t tile) {
+        const int64_t c0 = tile * SCAN_CT;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int piece = k * 256 + threadIdx.x;
+            const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
+            const int64_t j = c0 + sc < n ? c0 + sc : n - 1;
+            const uint4 f = *reinterpret_cast<const uint4 *>(zb + j * 2 * DPB + off * 8);
+            vals[k][0] = f.x; vals[k][1] = f.y; vals[k][2] = f.z; vals[k][3] = f.w;
+        }
+        if (threadIdx.x < SCAN_CT) {
+            const int64_t jj = c0 + threadIdx.x;
+            nval = 3.0e38f;                                    // beyond the corpus: never kept
+            if (jj < n) {
+                const double nd = nrm[jj] * (1.0 - eps);
+                nval = (float)nd;
+                if ((double)nval > nd) nval = nextafterf(nval, -3.4e38f);
+            }
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int piece = k * 256 + threadIdx.x;
+            const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
+            *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + off * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
+        }
+        if (threadIdx.x < SCAN_CT) Ns[buf][threadIdx.x] = nval;
+    };
+    constexpr int EQ_CAP = 128;
+    __shared__ unsigned long long eb[4][EQ_CAP];
+    int qn = 0;                                                // pairs queued by this wave (wave-uniform)
+    auto flush = [&]() {                                       // wave-uniform call
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int m = qn < EQ_CAP ? qn : EQ_CAP;
+        for (int i = lane; i < m; i += 64) {
+            const unsigned long long e = eb[wave][i];
+            const int64_t row = (int64_t)(e >> 32);
+            const int32_t slot = atomicAdd(&cnt[row], 1);
+            if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = (int32_t)(e & 0xffffffffu);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (ec[wave] >= EQ_CAP / 2) flush();
+        qn = 0;
+    };
+    // Kept pairs go to a per-wave LDS queue first (the returning global atomic that reserves a list slot costs
+    // microseconds, too much inside the MFMA stream; the queue is flushed at tile ends).  The signs of a lane's 32
+    // accumulator entries (two column tiles) are packed into one word; lanes then take their set bits one per round and
+    // get queue positions from the round's ballot: no LDS atomics, a handful of branches per 2 048 pairs.
+    auto keep_pairs = [&](const f32x16v &acc0, const f32x16v &acc1, int64_t cand0) {
+        unsigned any = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) any |= __float_as_uint(acc0[q]) | __float_as_uint(acc1[q]);
+        if (!__ballot((any & 0x80000000u) != 0)) return;       // wave-uniform: nothing to keep in these 2 048 pairs
+        unsigned bits = 0;                                     // bit q: acc0[q] < 0, bit 16 + q: acc1[q] < 0
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            bits |= (__float_as_uint(acc0[q]) >> 31) << q;
+            bits |= (__float_as_uint(acc1[q]) >> 31) << (16 + q);
+        }
+        for (;;) {
+            const unsigned long long hit = __ballot(bits != 0);
+            if (!hit) break;
+            if (bits != 0) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int q = b & 15;
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
+                const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int32_t cand = (int32_t)(cand0 + (b >> 4) * 32 + r);
+                if (pos < EQ_CAP) {
+                    eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
+                } else {                                       // queue full (masses of duplicates): straight to the list
+                    const int32_t slot = atomicAdd(&cnt[row], 1);
+                    if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                }
+            }
+            qn += __builtin_popcountll(hit);
+        }
+    };
+    fetch(tile_lo);
+    put((int)(tile_lo & 1));
+    __syncthreads();
+    for (int64_t tile = tile_lo; tile < n_tiles; ++tile) {
+        const int buf = (int)(tile & 1);
+        if (tile + 1 < n_tiles) fetch(tile + 1);
+#pragma unroll
+        for (int t = 0; t < SCAN_CT / 32; t += 2) {           // two column tiles in flight: independent accumulators
+            f32x16v acc0, acc1;
+            const float n0 = Ns[buf][t * 32 + r], n1 = Ns[buf][(t + 1) * 32 + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = n0 - uq[i]; acc1[i] = n1 - uq[i]; }
+            const unsigned char *b0 = &Ts[buf][(t * 32 + r) * ROWB + h * 16], *b1 = b0 + 32 * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const bf16x8k y0h = *reinterpret_cast<const bf16x8k *>(b0 + ks * 32);
+                const bf16x8k y0l = *reinterpret_cast<const bf16x8k *>(b0 + 2 * DPB + ks * 32);
+                const bf16x8k y1h = *reinterpret_cast<const bf16x8k *>(b1 + ks * 32);
+                const bf16x8k y1l = *reinterpret_cast<const bf16x8k *>(b1 + 2 * DPB + ks * 32);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y1h, acc1, 0, 0, 0);
+            }
+            keep_pairs(acc0, acc1, tile * SCAN_CT + t * 32);       // a negative entry = a pair to keep
+        }
+        if (qn >= EQ_CAP / 2) flush();
         if (tile + 1 < n_tiles) put(buf ^ 1);
         __syncthreads();
     }
@@ -451,8 +655,10 @@ extern "C" size_t geo_knn_workspace_bytes(int64_t n, int32_t d) {
                geo::align_up((size_t)n * sizeof(double)) + 1024;
     if (filter_applies(n, p.dp)) {
         const size_t m = ((size_t)n + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        const size_t dpb = p.dp < 16 ? 16 : p.dp;
         b += geo::align_up(m * p.dp * sizeof(float)) + geo::align_up(m * sizeof(double)) + geo::align_up((size_t)n * 8) +
-             geo::align_up((size_t)n * 4) + geo::align_up((size_t)n * FILTER_CAP * 4) + 256;
+             geo::align_up((size_t)n * 4) + geo::align_up((size_t)n * FILTER_CAP * 4) + 256 +
+             geo::align_up((size_t)n * 2 * dpb * sizeof(unsigned short));
     }
     return b;
 }
@@ -494,13 +700,17 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         int32_t *cnt = ar.take<int32_t>((size_t)n);
         int32_t *list = ar.take<int32_t>((size_t)n * FILTER_CAP);
         int32_t *overflow = ar.take<int32_t>(16);
-        if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow) {
+        const int dpb = p.dp < 16 ? 16 : p.dp;
+        const bool bf16_scan = geo::options().knn_filter != 2;         // 2: the float32 matrix-core scan (comparison runs)
+        unsigned short *zb = ar.take<unsigned short>((size_t)n * 2 * dpb);
+        if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow || !zb) {
             geo::set_error("geo_knn_topk: workspace %zu too small", ws_bytes);
             return GEO_E_WORKSPACE;
         }
         // a d-term float32 dot product errs by < (d + 2) 2^-24 |x||y|, |x||y| <= (|x|^2 + |y|^2) / 2, and the float32
         // test adds a few more roundings of the same size: 16x margin
-        const double eps = 16.0 * (p.dp + 2) * 5.9604644775390625e-08;
+        // (the bf16 scan keeps 16 bits of every coordinate: its products err by < 2^-16 (|x|^2 + |y|^2) on top, 4x margin)
+        const double eps = 16.0 * (p.dp + 2) * 5.9604644775390625e-08 + (bf16_scan ? 4.0 * 1.52587890625e-05 : 0.0);
         GEO_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, stream));
         knn_subset_kernel<<<geo::grid_for(m * p.dp, 256, 4096), 256, 0, stream>>>(zp32, nrm, n, p.dp, FILTER_STRIDE, m, zs32, nrm_s);
         GEO_LAUNCH_CHECK();
@@ -513,6 +723,13 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         GEO_LAUNCH_CHECK();
         const int splits = (int)((int64_t)16384 / ((rows + 127) / 128) > 1 ? ((int64_t)16384 / ((rows + 127) / 128) > 64 ? 64 : (int64_t)16384 / ((rows + 127) / 128)) : 1);
         const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
+        if (bf16_scan) {
+            knn_split_kernel<<<geo::grid_for((int64_t)n * dpb, 256, 4096), 256, 0, stream>>>(zp32, n, p.dp, dpb, zb);
+            GEO_LAUNCH_CHECK();
+            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+            else knn_scan_bf16_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        } else
         if (p.dp == 8) knn_scan_kernel<8, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 16) knn_scan_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 32) knn_scan_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
