@@ -111,6 +111,19 @@ int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, const float *we
                   void *ws, size_t ws_bytes, int32_t *status_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Medoid update over a resident all-pairs matrix (extension: the reference stops after seeding + assignment,
+ * src/geo/kmeans_optimized.py:141-183).  D f32 [n][ld] holds geodesic distances (rows filled by
+ * geo_sssp_multi).  geo_cluster_costs: cost_out[i] = sum over the members j of i's cluster of D[i][j]^power
+ * (power 1 or 2, fp64; members of cluster c = order[offsets[c] .. offsets[c+1]), `assign` i32 [n]).
+ * geo_rows_argmin: for every column j the smallest D[rows[m]][j] and the first m attaining it (np.argmin's tie rule),
+ * i.e. the re-assignment to the medoids `rows`.
+ * ------------------------------------------------------------------------------------------ */
+int geo_cluster_costs(const float *D, int64_t ld, const int32_t *assign, const int32_t *order,
+                      const int32_t *offsets, int32_t n, int32_t power, double *cost_out, void *stream);
+int geo_rows_argmin(const float *D, int64_t ld, const int32_t *rows, int32_t n_rows, int32_t n,
+                    float *dmin_out, int32_t *argmin_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * kNN search.  Replaces sklearn NearestNeighbors.kneighbors as called from
  * src/geo/knn_graph_optimized.py:40-42: exact n_neighbors nearest corpus rows (self included) of the
  * query rows [row0,row1) of z, ranked on fp64 squared distances, ties ordered by index.

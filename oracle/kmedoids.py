@@ -112,3 +112,62 @@ def fit_kmedoids_single_pass(W, K: int = 512, seed: int = 42):
         absorb(len(centers) - 1)                # the last centre gets no solve inside k++
     # (after an early break every listed centre has already been absorbed)
     return np.array(centers, dtype=int), arg, quantization_error_from(d_min)
+
+
+# ---- extension without a reference implementation: medoid update over the all-pairs matrix ------
+def all_pairs(W) -> np.ndarray:
+    """f32 [n, n]: scipy Dijkstra from every node (dijkstra_multi_source over range(n))."""
+    from .sssp import dijkstra_multi_source
+    return dijkstra_multi_source(W, np.arange(W.shape[0]))
+
+
+def _tree_sum_rows(X: np.ndarray) -> np.ndarray:
+    """Row sums of fp64 X [r, m] in the order of geo_cluster_costs: 64 strided partial sums (element l, l+64, ...
+    added in that order), then the xor butterfly 32, 16, ..., 1."""
+    r, m = X.shape
+    acc = np.zeros((r, 64), dtype=np.float64)
+    for b in range(0, m, 64):
+        blk = X[:, b:b + 64]
+        acc[:, :blk.shape[1]] = acc[:, :blk.shape[1]] + blk
+    lanes = np.arange(64)
+    off = 32
+    while off >= 1:
+        acc = acc + acc[:, lanes ^ off]
+        off >>= 1
+    return acc[:, 0]
+
+
+def medoid_update(D: np.ndarray, assign: np.ndarray, medoids: np.ndarray, power: int = 2):
+    """Per cluster the member with the smallest sum of D[i][j]^power over the members (lowest index on ties);
+    an empty cluster keeps its medoid.  Returns (new medoids, cost f64 [n])."""
+    n, K = D.shape[0], len(medoids)
+    cost = np.zeros(n, dtype=np.float64)
+    new = np.array(medoids, dtype=np.int64).copy()
+    for c in range(K):
+        members = np.flatnonzero(assign == c)
+        if members.size == 0:
+            continue
+        sub = D[np.ix_(members, members)].astype(np.float64)
+        if power == 2:
+            sub = sub * sub
+        cost[members] = _tree_sum_rows(sub)
+        new[c] = members[int(np.argmin(cost[members]))]
+    return new, cost
+
+
+def voronoi_iteration(W, medoids0, max_iter: int = 10, power: int = 2, D: np.ndarray = None):
+    """Assignment / medoid update until the medoids stop changing.  Returns (medoids, assign, qe, history)."""
+    if D is None:
+        D = all_pairs(W)
+    med = np.asarray(medoids0, dtype=np.int64)
+    assign = np.argmin(D[med], axis=0)
+    history = [quantization_error_from(D[med][assign, np.arange(D.shape[0])])]
+    for _ in range(max_iter):
+        new, _ = medoid_update(D, assign, med, power)
+        if np.array_equal(new, med):
+            break
+        med = new
+        assign = np.argmin(D[med], axis=0)
+        history.append(quantization_error_from(D[med][assign, np.arange(D.shape[0])]))
+    return med, assign, history[-1], history
+

@@ -336,3 +336,23 @@ def test_fixed_point_solve_declines_and_falls_back():
     got = _with_option(b"sssp_group", 0, lambda: dijkstra_multi_source(L, ls))
     np.testing.assert_array_equal(got, osp.dijkstra_multi_source(L, ls))
     assert _lib.load().geo_sssp_last_profile(None, None) < 2000
+
+
+def test_large_graph_takes_fixed_point_layout_and_falls_back_to_64_source_batches():
+    """Beyond the L2-sized range (n * 128 B > 12 MB) the 16/32-source layout is chosen only as the carrier of the
+    fixed-point solve; weights it declines are solved by the 64-source fp64 kernel.  Both equal the oracle."""
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from vqvae_amd import _lib
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source
+    n = 100003
+    W, _ = okn.build_knn_graph(latents(n, 16, 23), k=12, mode="distance", sym="union")     # short geodesics
+    src = np.random.RandomState(9).choice(n, 40, replace=False)
+    np.testing.assert_array_equal(dijkstra_multi_source(W, src), osp.dijkstra_multi_source(W, src))
+    assert _lib.load().geo_sssp_last_profile(None, None) == 2032          # 32-bit fixed point
+    Wide = W.copy()
+    Wide.data = (Wide.data * np.where(np.arange(Wide.nnz) % 5 == 0, 1e-4, 1.0)).astype(np.float32)
+    Wide = Wide.maximum(Wide.T).tocsr()
+    np.testing.assert_array_equal(dijkstra_multi_source(Wide, src), osp.dijkstra_multi_source(Wide, src))
+    assert _lib.load().geo_sssp_last_profile(None, None) == 64            # declined -> 64 sources per batch
+

@@ -235,3 +235,31 @@ def test_cosine_knn_graph_equals_reference(golden):
             if mode == "distance":
                 assert np.abs(W.data - g[f"{tag}/data"]).max() <= 5e-7
         np.testing.assert_array_equal(info["indices"], g[f"{name}/cosine/nbr_indices"])
+
+
+def test_voronoi_iteration_oracle_properties():
+    """Extension without a reference: the numpy restatement against brute force on a small graph."""
+    import math
+    from oracle import kmedoids as okm
+    from oracle import knn as okn
+    z = np.random.RandomState(3).randn(300, 6).astype(np.float32)
+    W, _ = okn.build_knn_graph(z, k=6, mode="distance", sym="union")
+    mask = okn.largest_connected_component(W)
+    W = W[mask][:, mask].tocsr()
+    n = W.shape[0]
+    D = okm.all_pairs(W)
+    np.testing.assert_array_equal(D, D.T)                                   # undirected graph
+    med0 = np.random.RandomState(0).choice(n, 9, replace=False)
+    assign0 = np.argmin(D[med0], axis=0)
+    new, cost = okm.medoid_update(D, assign0, med0, power=2)
+    for c in range(9):
+        members = np.flatnonzero(assign0 == c)
+        exact = [math.fsum(float(D[i, j]) ** 2 for j in members) for i in members]
+        np.testing.assert_allclose(cost[members], exact, rtol=1e-13)
+        assert new[c] == members[int(np.argmin(cost[members]))]
+    med, assign, qe, hist = okm.voronoi_iteration(W, med0, max_iter=20, D=D)
+    assert all(b <= a for a, b in zip(hist, hist[1:])) and qe == hist[-1]
+    again, _ = okm.medoid_update(D, assign, med, power=2)                   # converged: a further update is the identity
+    np.testing.assert_array_equal(again, med)
+    X = np.random.RandomState(1).rand(7, 333)
+    np.testing.assert_allclose(okm._tree_sum_rows(X), X.sum(axis=1), rtol=1e-14)

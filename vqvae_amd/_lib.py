@@ -32,6 +32,8 @@ _SIGNATURES = {
     "geo_sssp_last_profile": (ctypes.c_int, [c_p, c_p]),
     "geo_sssp_single_update": (ctypes.c_int, [c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i32, c_p, sz, c_p, c_p]),
     "geo_kpp_workspace_bytes": (sz, [i32]),
+    "geo_cluster_costs": (ctypes.c_int, [c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p]),
+    "geo_rows_argmin": (ctypes.c_int, [c_p, i64, c_p, i32, i32, c_p, c_p, c_p]),
     "geo_kpp_resident_max_nodes": (i32, []),
     "geo_kpp_chain": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p, sz, c_p, c_p]),
     "geo_knn_workspace_bytes": (sz, [i64, i32]),

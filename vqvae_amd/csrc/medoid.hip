@@ -1,0 +1,78 @@
+// medoid.hip -- medoid update / re-assignment over a resident all-pairs geodesic matrix (gfx950).
+//
+// The reference stops after the k-means++ seeding and one assignment (src/geo/kmeans_optimized.py:141-183); its notes
+// list the medoid update as the missing step ("iterative medoid update (Voronoi/PAM) over D").
+// With 288 GB of HBM the full N x N float32 matrix of a 60 000-latent set (14.4 GB) stays resident: the K-source solve
+// fills it 512 rows at a time, and one Voronoi iteration is
+//   cost[i]   = sum over the members j of i's cluster of D[i][j]^power        (cluster_cost_kernel)
+//   medoid[c] = the member of c with the smallest cost, lowest index on ties   (host side: two scatter-min passes)
+//   assign[j] = argmin_c D[medoid[c]][j], first medoid on ties                 (rows_argmin_kernel)
+// There is no reference implementation: parity is against the numpy restatement in oracle/kmedoids.py
+// (voronoi_iteration), see DESIGN.md "Extensions".
+#include "geo_common.h"
+
+namespace {
+
+// One wave per row i.  members = order[offsets[c] .. offsets[c+1]) are the nodes of i's cluster c (ascending node
+// index inside a cluster); lane l takes members l, l + 64, ... in that order, fp64 accumulation of the float32 entries
+// raised to `power` (1 or 2; the squares are exact in fp64), then the xor butterfly 32, 16, ..., 1: a fixed summation
+// tree, the same for every run.
+__global__ __launch_bounds__(256) void cluster_cost_kernel(const float *__restrict__ D, int64_t ld,
+                                                          const int32_t *__restrict__ assign,
+                                                          const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ offsets, int32_t n, int32_t power,
+                                                          double *__restrict__ cost) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int32_t c = assign[i];
+    const int32_t m0 = offsets[c], m1 = offsets[c + 1];
+    const float *row = D + i * ld;
+    double acc = 0.0;
+    for (int32_t m = m0 + lane; m < m1; m += 64) {
+        const double x = (double)row[order[m]];
+        acc += power == 2 ? x * x : x;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) cost[i] = acc;
+}
+
+// Thread per column j: the first row (in the order given) with the smallest D[rows[m]][j]; coalesced across j.
+__global__ __launch_bounds__(256) void rows_argmin_kernel(const float *__restrict__ D, int64_t ld,
+                                                         const int32_t *__restrict__ rows, int32_t n_rows, int32_t n,
+                                                         float *__restrict__ dmin, int32_t *__restrict__ argmin) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float best = __int_as_float(0x7f800000);
+    int32_t arg = 0;
+    for (int32_t m = 0; m < n_rows; ++m) {
+        const float v = D[(int64_t)rows[m] * ld + j];
+        if (v < best) { best = v; arg = m; }                    // strict: the first index wins ties (np.argmin)
+    }
+    if (dmin) dmin[j] = best;
+    if (argmin) argmin[j] = arg;
+}
+
+}  // namespace
+
+extern "C" int geo_cluster_costs(const float *D, int64_t ld, const int32_t *assign, const int32_t *order,
+                                 const int32_t *offsets, int32_t n, int32_t power, double *cost_out, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(D && assign && order && offsets && cost_out, "geo_cluster_costs: null pointer");
+    GEO_REQUIRE(n > 0 && ld >= n && (power == 1 || power == 2), "geo_cluster_costs: bad n=%d ld=%lld power=%d", n,
+                (long long)ld, power);
+    cluster_cost_kernel<<<(unsigned)((n + 3) / 4), 256, 0, stream>>>(D, ld, assign, order, offsets, n, power, cost_out);
+    GEO_LAUNCH_CHECK();
+    return GEO_OK;
+}
+
+extern "C" int geo_rows_argmin(const float *D, int64_t ld, const int32_t *rows, int32_t n_rows, int32_t n,
+                               float *dmin_out, int32_t *argmin_out, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(D && rows && (dmin_out || argmin_out), "geo_rows_argmin: null pointer");
+    GEO_REQUIRE(n > 0 && n_rows > 0 && ld >= n, "geo_rows_argmin: bad n=%d rows=%d ld=%lld", n, n_rows, (long long)ld);
+    rows_argmin_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, ld, rows, n_rows, n, dmin_out, argmin_out);
+    GEO_LAUNCH_CHECK();
+    return GEO_OK;
+}

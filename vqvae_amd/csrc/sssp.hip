@@ -998,7 +998,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
             g_last_sweep_ms = 0.0;                       // the fp64 solve below is the one that counts
         }
         // a graph this large took 16-source batches only for the fixed-point solve: the fp64 solve runs 64 per batch
-        if (force_sb == 0 && opt.sssp_sb == 0 && (size_t)n * 128 > ((size_t)12 << 20))
+        if (force_sb == 0 && opt.sssp_sb != 16 && opt.sssp_sb != 64 && (size_t)n * 128 > ((size_t)12 << 20))
             return sssp_multi_impl(indptr, indices, weights, n, nnz, sources, n_sources, D_out, P_out, dmin_out,
                                    argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }

@@ -327,3 +327,76 @@ def fit_kmedoids_with_connectivity_check(W, K: int = 512, init: str = "kpp", see
     medoids, assign, qe = fit_kmedoids_optimized(G, K=K, init=init, seed=seed)
     metadata.update({"n_medoids": len(medoids), "quantization_error": qe, "method": "optimized_kmedoids"})
     return medoids, assign, qe, metadata
+
+
+# ---- extension: medoid update (Voronoi iteration) over the resident all-pairs matrix -------------------------------------
+def medoid_update_device(D: torch.Tensor, assign: torch.Tensor, medoids: torch.Tensor, power: int = 2):
+    """One medoid update: per cluster the member with the smallest sum of D[i][j]^power over the cluster's members
+    (lowest node index on ties); a cluster without members keeps its medoid.  D f32 [n,n], assign i32/i64 [n],
+    medoids i32 [K], all on the GPU.  Returns (new medoids i32 [K], cost f64 [n])."""
+    lib = _lib.load()
+    dev = D.device
+    n, K = int(D.shape[0]), int(medoids.numel())
+    a64 = assign.to(torch.int64)
+    a32 = assign.to(torch.int32).contiguous()
+    order = torch.argsort(a64, stable=True).to(torch.int32).contiguous()        # members ascending inside a cluster
+    counts = torch.bincount(a64, minlength=K)
+    offsets = torch.zeros(K + 1, dtype=torch.int32, device=dev)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    cost = torch.empty(n, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_cluster_costs(ptr(D), D.stride(0), ptr(a32), ptr(order), ptr(offsets), n, int(power),
+                                         ptr(cost), stream_ptr()), "geo_cluster_costs")
+    cmin = torch.full((K,), float("inf"), dtype=torch.float64, device=dev).scatter_reduce(0, a64, cost, "amin")
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    cand = torch.where(cost == cmin[a64], idx, torch.full_like(idx, n))
+    first = torch.full((K,), n, dtype=torch.int64, device=dev).scatter_reduce(0, a64, cand, "amin")
+    new = torch.where(first < n, first, medoids.to(torch.int64)).to(torch.int32)
+    return new, cost
+
+
+def assign_from_rows_device(D: torch.Tensor, medoids: torch.Tensor):
+    """(dmin f32 [n], argmin i32 [n]): nearest medoid row of D per node, first medoid on ties."""
+    lib = _lib.load()
+    dev = D.device
+    n = int(D.shape[1])
+    rows = medoids.to(torch.int32).contiguous()
+    dmin = torch.empty(n, dtype=torch.float32, device=dev)
+    arg = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_rows_argmin(ptr(D), D.stride(0), ptr(rows), int(rows.numel()), n, ptr(dmin), ptr(arg),
+                                       stream_ptr()), "geo_rows_argmin")
+    return dmin, arg
+
+
+def fit_kmedoids_voronoi(W, K: int = 512, init: str = "kpp", seed: int = 42, max_iter: int = 10, power: int = 2,
+                         D: Optional[torch.Tensor] = None):
+    """fit_kmedoids_optimized followed by medoid updates until the medoids stop changing (at most max_iter updates).
+
+    Extension of the reference (its k-medoids is seeding + one assignment, kmeans_optimized.py:141-183; SURVEY.md section 8
+    f4): the all-pairs geodesic matrix is formed once on the GPU (all_pairs_geodesic_device) unless given, every
+    iteration is one geo_cluster_costs + one geo_rows_argmin.  power=2 minimises the reference's quantisation error
+    (sum of squared distances), which therefore never increases.  Returns (medoids, assign, qe, history) with
+    history = [qe after the initial assignment, after update 1, ...]."""
+    from .geo_shortest_paths import all_pairs_geodesic_device
+    G = _to_device_graph(W)
+    dev = G.indptr.device
+    medoids0, assign0, qe0 = fit_kmedoids_optimized(W, K=K, init=init, seed=seed)
+    if D is None:
+        D = all_pairs_geodesic_device(G)
+    med = torch.from_numpy(np.asarray(medoids0, dtype=np.int32)).to(dev)
+    assign = torch.from_numpy(np.asarray(assign0, dtype=np.int32)).to(dev)
+    history = [qe0]
+    for _ in range(max_iter):
+        new, _ = medoid_update_device(D, assign, med, power)
+        if bool((new == med).all()):
+            break
+        med = new
+        dmin, assign = assign_from_rows_device(D, med)
+        history.append(_qe_from(dmin.cpu().numpy()))
+    medoids = med.cpu().numpy().astype(int)
+    assign_h = assign.cpu().numpy().astype(int)
+    _print_sizes(assign_h, len(medoids))
+    print(f"[kmedoids] Voronoi iterations: {len(history) - 1}, qe {history[0]:.3f} -> {history[-1]:.3f}")
+    return medoids, assign_h, history[-1], history
+
