@@ -122,6 +122,13 @@ int geo_cluster_costs(const float *D, int64_t ld, const int32_t *assign, const i
                       const int32_t *offsets, int32_t n, int32_t power, double *cost_out, void *stream);
 int geo_rows_argmin(const float *D, int64_t ld, const int32_t *rows, int32_t n_rows, int32_t n,
                     float *dmin_out, int32_t *argmin_out, void *stream);
+/* geo_attach_argmin: geodesic assignment of points outside the graph (the step the reference's notes call
+ * assign_codes_val_geodesic.py, docs/results/cifar10_quantization_analysis.md:147; not in its repository).  Point v is
+ * joined to graph nodes nbr[v][0..k) by edges of length len[v][0..k) (nbr < 0: no edge); Dt f32 [n][ld] holds the medoids'
+ * distance rows transposed ([node][medoid]).  dist_out[v] = min over medoids m and edges u of len[v][u] + Dt[nbr[v][u]][m],
+ * arg_out[v] = the first medoid attaining it (0 if none is reachable). */
+int geo_attach_argmin(const float *Dt, int64_t ld, int32_t K, const int32_t *nbr, const float *len, int32_t k,
+                      int64_t n_new, float *dist_out, int32_t *arg_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * kNN search.  Replaces sklearn NearestNeighbors.kneighbors as called from

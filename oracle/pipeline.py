@@ -68,3 +68,34 @@ def build_codebook(z4: np.ndarray, decoder_sd: Mapping, norm_type: str, output_i
     return {"codes": codes.reshape(N, H, Wd), "medoid_indices": medoids.astype(np.int32),
             "z_medoid": z_lcc[medoids].astype(np.float32), "W_lcc": sparse.csr_matrix(W_lcc),
             "mask_lcc": mask, "qe": qe, "edges": edges, "edge_lengths": lengths}
+
+
+# ---- extension without a reference implementation: codes of latents outside the graph -------
+def attach_neighbors(z_new: np.ndarray, z_graph: np.ndarray, k: int):
+    """(idx [V, k'], d2 f64 [V, k']): the k' = min(k, n) nearest graph nodes, fp64 squared distances accumulated dimension
+    by dimension, ties by node index (vqvae_amd/training/assign_codes_val_geodesic.py: attach_neighbors_device)."""
+    a, b = z_new.astype(np.float64), z_graph.astype(np.float64)
+    acc = np.zeros((a.shape[0], b.shape[0]), dtype=np.float64)
+    for c in range(b.shape[1]):
+        diff = a[:, c:c + 1] - b[:, c][None, :]
+        acc += diff * diff
+    order = np.argsort(acc, axis=1, kind="stable")
+    kk = min(int(k), b.shape[0])
+    idx = order[:, :kk]
+    return idx.astype(np.int32), np.take_along_axis(acc, idx, axis=1)
+
+
+def assign_new_latents(z_new: np.ndarray, z_graph: np.ndarray, W_geo, medoids, k: int = 20, lengths: np.ndarray = None):
+    """codes [V], dist f32 [V]: dist(v, m) = min_u len(v, u) + D[m][u] over the k attachments (float32 additions),
+    first medoid on ties.  `lengths` f32 [V, k] (e.g. pull-back lengths from oracle.metric) or Euclidean when None."""
+    from .sssp import dijkstra_multi_source
+    idx, d2 = attach_neighbors(z_new, z_graph, k)
+    if lengths is None:
+        lengths = np.sqrt(d2).astype(np.float32)
+    D = dijkstra_multi_source(W_geo, np.asarray(medoids))                # f32 [K, n]
+    V = z_new.shape[0]
+    dist = np.full((len(medoids), V), np.inf, dtype=np.float32)
+    for u in range(idx.shape[1]):
+        cand = (lengths[:, u][None, :] + D[:, idx[:, u]]).astype(np.float32)
+        dist = np.minimum(dist, cand)
+    return np.argmin(dist, axis=0), dist.min(axis=0), idx, lengths

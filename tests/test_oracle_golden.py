@@ -263,3 +263,32 @@ def test_voronoi_iteration_oracle_properties():
     np.testing.assert_array_equal(again, med)
     X = np.random.RandomState(1).rand(7, 333)
     np.testing.assert_allclose(okm._tree_sum_rows(X), X.sum(axis=1), rtol=1e-14)
+
+
+def test_held_out_assignment_oracle_against_explicit_graph_extension():
+    """assign_new_latents (extension) = shortest paths on the graph with the new node and its k attachment
+    edges added explicitly (one new node at a time, so new nodes never see each other)."""
+    import scipy.sparse as sp
+    from oracle import kmedoids as okm
+    from oracle import knn as okn
+    from oracle import pipeline as opl
+    from oracle import sssp as osp
+    rs = np.random.RandomState(5)
+    z = rs.randn(260, 5).astype(np.float32)
+    W, _ = okn.build_knn_graph(z[:240], k=6, mode="distance", sym="union")
+    mask = okn.largest_connected_component(W)
+    W = W[mask][:, mask].tocsr()
+    zg, znew = z[:240][mask], z[240:]
+    n = W.shape[0]
+    med, _, _ = okm.fit_kmedoids_optimized(W, K=7, init="kpp", seed=0)
+    codes, dist, idx, lengths = opl.assign_new_latents(znew, zg, W, med, k=4)
+    brute = np.sqrt(((znew[:, None, :].astype(np.float64) - zg[None, :, :].astype(np.float64)) ** 2).sum(-1))
+    np.testing.assert_array_equal(np.sort(idx, axis=1), np.sort(np.argsort(brute, axis=1, kind="stable")[:, :4], axis=1))
+    for v in range(znew.shape[0]):
+        rows = np.concatenate([np.full(4, n), idx[v]])
+        cols = np.concatenate([idx[v], np.full(4, n)])
+        A = sp.csr_matrix((np.concatenate([lengths[v], lengths[v]]), (rows, cols)), shape=(n + 1, n + 1))
+        Wx = (sp.block_diag([W, sp.csr_matrix((1, 1))]).tocsr() + A).tocsr().astype(np.float32)
+        d = osp.dijkstra_multi_source(Wx, np.asarray(med))[:, n]
+        np.testing.assert_allclose(dist[v], d.min(), rtol=1e-6)
+        assert d[codes[v]] <= d.min() * (1 + 1e-6)

@@ -54,7 +54,55 @@ __global__ __launch_bounds__(256) void rows_argmin_kernel(const float *__restric
     if (argmin) argmin[j] = arg;
 }
 
+// One wave per new point v: the k attachment edges (nbr[v][u], len[v][u]) join v to the graph; its geodesic distance to
+// medoid m is min_u len[v][u] + Dt[nbr[v][u]][m] (Dt = the medoids' distance rows transposed: [node][medoid], so the 64
+// lanes read 64 consecutive medoids of one node).  Smallest distance and FIRST medoid attaining it; nbr < 0 = no edge.
+__global__ __launch_bounds__(256) void attach_argmin_kernel(const float *__restrict__ Dt, int64_t ld, int32_t K,
+                                                           const int32_t *__restrict__ nbr, const float *__restrict__ len,
+                                                           int32_t k, int64_t n_new, float *__restrict__ dist_out,
+                                                           int32_t *__restrict__ arg_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_new) return;
+    float best = __int_as_float(0x7f800000);
+    int32_t arg = 0x7fffffff;
+    for (int32_t m0 = 0; m0 < K; m0 += 64) {
+        const int32_t m = m0 + lane;
+        float dm = __int_as_float(0x7f800000);
+        if (m < K) {
+            for (int32_t u = 0; u < k; ++u) {
+                const int32_t node = nbr[v * k + u];           // wave-uniform
+                if (node < 0) continue;
+                const float cand = len[v * k + u] + Dt[(int64_t)node * ld + m];
+                dm = cand < dm ? cand : dm;
+            }
+        }
+        if (dm < best) { best = dm; arg = m; }                 // ascending m per lane: strict < keeps the first
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {                  // (distance, medoid index) lexicographic minimum
+        const float ob = __shfl_xor(best, off, 64);
+        const int32_t oa = __shfl_xor(arg, off, 64);
+        if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) {
+        dist_out[v] = best;
+        arg_out[v] = arg == 0x7fffffff ? 0 : arg;              // no finite path: np.argmin of an all-inf column is 0
+    }
+}
+
 }  // namespace
+
+extern "C" int geo_attach_argmin(const float *Dt, int64_t ld, int32_t K, const int32_t *nbr, const float *len, int32_t k,
+                                 int64_t n_new, float *dist_out, int32_t *arg_out, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(Dt && nbr && len && dist_out && arg_out, "geo_attach_argmin: null pointer");
+    GEO_REQUIRE(K > 0 && k > 0 && ld >= K && n_new >= 0, "geo_attach_argmin: bad K=%d k=%d ld=%lld", K, k, (long long)ld);
+    if (n_new == 0) return GEO_OK;
+    attach_argmin_kernel<<<(unsigned)((n_new + 3) / 4), 256, 0, stream>>>(Dt, ld, K, nbr, len, k, n_new, dist_out, arg_out);
+    GEO_LAUNCH_CHECK();
+    return GEO_OK;
+}
 
 extern "C" int geo_cluster_costs(const float *D, int64_t ld, const int32_t *assign, const int32_t *order,
                                  const int32_t *offsets, int32_t n, int32_t power, double *cost_out, void *stream_) {
