@@ -30,6 +30,7 @@ namespace {
 constexpr int TS = 32;          // samples per tile (= one 32-row MFMA slice for primal, one for tangent)
 constexpr int NC = 128;         // output columns per mid-kernel workgroup (4 waves x 32)
 constexpr int MAX_BLOCKS = 4;   // input pixels feeding one output pixel (2x2 input)
+constexpr int FRONT_MAX_N1 = 1024;   // columns of the first pre-activation (4 pixels x c1 <= 256 channels)
 constexpr int BACK_TS = 8;      // samples per back-kernel workgroup
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
     __shared__ float zp[TS][DMAX + 1];
     __shared__ float dz[TS][DMAX + 1];
     __shared__ int valid_s[TS];
+    __shared__ double ps[FRONT_MAX_N1][4];                  // per-column statistics before the pixel reduction
     const int tile = blockIdx.x;
     const int group = tile / tiles_per_group, tg = tile % tiles_per_group;
     const int chunk = group >> 1, side = group & 1;
@@ -161,18 +163,26 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
                 sx += x; sxx += (double)x * x; st += t; sxt += (double)x * t;
             }
         }
-        if (want_stats) {
-            double *p = partial + ((size_t)tile * n1 + n) * 4;
-            p[0] = sx; p[1] = sxx; p[2] = st; p[3] = sxt;
+        if (want_stats) { ps[n][0] = sx; ps[n][1] = sxx; ps[n][2] = st; ps[n][3] = sxt; }
+    }
+    if (want_stats) {                                       // the four pixels of a channel, in pixel order: [tile][c1][4]
+        __syncthreads();
+        const int c1 = n1 / 4;
+        for (int c = threadIdx.x; c < c1; c += 256) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) { a0 += ps[px * c1 + c][0]; a1 += ps[px * c1 + c][1]; a2 += ps[px * c1 + c][2]; a3 += ps[px * c1 + c][3]; }
+            double *p = partial + ((size_t)tile * c1 + c) * 4;
+            p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------- norm constants
 // mode 1 (batch statistics): reduce the per-tile partial sums of a group over tiles and pixels.
-// partial: [tile][npx*C][4] fp64.  consts: [group][C].
+// partial: [tile][npx_stored*C][4] fp64 (npx_stored = 1 when the producer summed a tile's pixels).  consts: [group][C].
 __global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__restrict__ partial, int tiles_per_group,
-                                                            int npx, int C, int64_t e_base, int64_t n_edges,
+                                                            int npx_stored, int npx, int C, int64_t e_base, int64_t n_edges,
                                                             int batch, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps,
                                                             NormConst *__restrict__ consts, int n_groups,
@@ -185,8 +195,8 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__res
         if (cnt < 0) cnt = 0;
         double sx = 0, sxx = 0, st = 0, sxt = 0;
         for (int t = 0; t < tiles_per_group; ++t)
-            for (int px = 0; px < npx; ++px) {
-                const double *p = partial + (((size_t)(g * tiles_per_group + t)) * npx * C + (size_t)px * C + c) * 4;
+            for (int px = 0; px < npx_stored; ++px) {      // (1 when the producing kernel already summed a tile's pixels)
+                const double *p = partial + (((size_t)(g * tiles_per_group + t)) * npx_stored * C + (size_t)px * C + c) * 4;
                 sx += p[0]; sxx += p[1]; st += p[2]; sxt += p[3];
             }
         const double n = (double)cnt * npx;
@@ -214,22 +224,26 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const double *__res
 //   running = (1 - m) * running + m * batch_stat, once per forward call, i.e. per (chunk, endpoint side) group IN ORDER
 // (riemannian_metric.py:57-58 calls the decoder for the start side, then the end side of each chunk).  One thread per
 // channel walks the groups of a pass sequentially (the rounding of every step is torch's).
-__global__ __launch_bounds__(1024) void running_update_kernel(const float2 *__restrict__ stats, int n_groups, int C, float m,
-                                                             float *__restrict__ running_mean, float *__restrict__ running_var) {
-    // one workgroup: all threads stage blocks of groups in LDS (coalesced, many loads in flight -- one thread per
-    // channel fetching its own rows took a millisecond for the 3 696 groups of a 60 000-latent build), then thread c
-    // applies the block's updates to channel c in order
-    __shared__ float2 blk[8192];                           // 64 KB
-    const int gpb = 8192 / C;                              // groups per block (C <= 1024 checked by the caller)
+__global__ __launch_bounds__(256) void running_update_kernel(const float2 *__restrict__ stats, int n_groups, int C, float m,
+                                                            float *__restrict__ running_mean, float *__restrict__ running_var) {
+    // One workgroup per 8 channels (one CU reading all 3.8 MB of a 60 000-latent build's statistics took 0.46 ms): all
+    // threads stage blocks of 512 groups x 8 channels in LDS, then 8 threads apply the block's updates in order.
+    constexpr int CH = 8, GB = 512;
+    __shared__ float2 blk[GB * CH];                        // 32 KB
+    const int c0 = blockIdx.x * CH;
+    const int nc = C - c0 < CH ? C - c0 : CH;
     float rm = 0.f, rv = 0.f;
-    if ((int)threadIdx.x < C) { rm = running_mean[threadIdx.x]; rv = running_var[threadIdx.x]; }
-    for (int g0 = 0; g0 < n_groups; g0 += gpb) {
-        const int ng = n_groups - g0 < gpb ? n_groups - g0 : gpb;
-        for (int i = threadIdx.x; i < ng * C; i += 1024) blk[i] = stats[(size_t)g0 * C + i];
+    if ((int)threadIdx.x < nc) { rm = running_mean[c0 + threadIdx.x]; rv = running_var[c0 + threadIdx.x]; }
+    for (int g0 = 0; g0 < n_groups; g0 += GB) {
+        const int ng = n_groups - g0 < GB ? n_groups - g0 : GB;
+        for (int i = threadIdx.x; i < ng * CH; i += 256) {
+            const int g = i / CH, c = i % CH;
+            blk[i] = c < nc ? stats[(size_t)(g0 + g) * C + c0 + c] : make_float2(0.f, -1.f);
+        }
         __syncthreads();
-        if ((int)threadIdx.x < C) {
+        if ((int)threadIdx.x < nc) {
             for (int g = 0; g < ng; ++g) {
-                const float2 st = blk[g * C + threadIdx.x];
+                const float2 st = blk[g * CH + threadIdx.x];
                 if (st.y < 0.f) continue;                  // empty or single-element batch
                 rm = (1.0f - m) * rm + m * st.x;
                 rv = (1.0f - m) * rv + m * st.y;
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(1024) void running_update_kernel(const float2 *__re
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < C) { running_mean[threadIdx.x] = rm; running_var[threadIdx.x] = rv; }
+    if ((int)threadIdx.x < nc) { running_mean[c0 + threadIdx.x] = rm; running_var[c0 + threadIdx.x] = rv; }
 }
 
 // mode 0 (none) / running statistics: one row of constants shared by every group.
@@ -648,11 +662,15 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     const int colw = wq * 32 + (lane & 31);
     const int lo = colw / c2, co = colw % c2;
     const float bias = b2[co];
+    // batch statistics: a lane's column is the same channel co in all four chunks of its wave, so their (and the two row
+    // halves') sums are added in registers; the four waves holding channel co (column quarters wq and wq ^ 2 of both wave
+    // groups) meet in LDS and are added in wave order: partial2 is [tile][c2][4], the tile's 16 pixels already summed
+    __shared__ double red[8][32][4];
+    double sx = 0, sxx = 0, st_ = 0, sxt = 0;
 #pragma unroll
     for (int lc = 0; lc < NL; ++lc) {
         const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
         const int op = tab.opix[ch][lo];
-        double sx = 0, sxx = 0, st_ = 0, sxt = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -661,13 +679,19 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
             tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
             if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
         }
-        if (want_stats) {
-            sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
-            st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
-            if (lane < 32) {
-                double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
-                p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
-            }
+    }
+    if (want_stats) {
+        sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+        st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+        if (lane < 32) { red[wave][lane][0] = sx; red[wave][lane][1] = sxx; red[wave][lane][2] = st_; red[wave][lane][3] = sxt; }
+        __syncthreads();
+        if (threadIdx.x < 64) {                                // thread = channel
+            const int w0 = threadIdx.x >> 5, l = threadIdx.x & 31;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a0 += red[w0 + 2 * w][l][0]; a1 += red[w0 + 2 * w][l][1]; a2 += red[w0 + 2 * w][l][2]; a3 += red[w0 + 2 * w][l][3]; }
+            double *p = partial2 + ((size_t)tile * c2 + threadIdx.x) * 4;
+            p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
         }
     }
 }
@@ -934,7 +958,7 @@ bool make_shape(const geo_decoder_desc *dc, Shape *s) {
     s->p_out = s->co * s->s_out * s->s_out;
     s->n1 = 4 * s->c1; s->n2 = 16 * s->c2;
     if (s->c2 <= 0 || NC % s->c2 != 0) return false;
-    if (s->c1 <= 0 || s->c1 > 1024) return false;          // (running_update_kernel: one thread per channel of a 1024-thread workgroup)
+    if (s->c1 <= 0 || 4 * s->c1 > FRONT_MAX_N1) return false;
     s->opix_per_chunk = NC / s->c2;
     if (s->opix_per_chunk > 16) s->opix_per_chunk = 16;
     s->n_chunks = 16 / s->opix_per_chunk;
@@ -1108,10 +1132,10 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
             finalize_batch_kernel<<<geo::grid_for(p_groups * s.c1, 256), 256, 0, stream>>>(
-                part1, pl.tiles_per_group, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups,
+                part1, pl.tiles_per_group, 1, 4, s.c1, e_base, n_edges, batch, dc->g1, dc->be1, dc->eps, k1, (int)p_groups,
                 track ? stats : nullptr);
             if (track)
-                running_update_kernel<<<1, 1024, 0, stream>>>(stats, (int)p_groups, s.c1, dc->momentum,
+                running_update_kernel<<<(unsigned)((s.c1 + 7) / 8), 256, 0, stream>>>(stats, (int)p_groups, s.c1, dc->momentum,
                                                                           const_cast<float *>(dc->rm1), const_cast<float *>(dc->rv1));
             GEO_LAUNCH_CHECK();
         }
@@ -1159,10 +1183,10 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
             finalize_batch_kernel<<<geo::grid_for(p_groups * s.c2, 256), 256, 0, stream>>>(
-                part2, pl.tiles_per_group, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups,
+                part2, pl.tiles_per_group, mid_all ? 1 : 16, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups,
                 track ? stats : nullptr);
             if (track)
-                running_update_kernel<<<1, 1024, 0, stream>>>(stats, (int)p_groups, s.c2, dc->momentum,
+                running_update_kernel<<<(unsigned)((s.c2 + 7) / 8), 256, 0, stream>>>(stats, (int)p_groups, s.c2, dc->momentum,
                                                                           const_cast<float *>(dc->rm2), const_cast<float *>(dc->rv2));
             GEO_LAUNCH_CHECK();
         }
