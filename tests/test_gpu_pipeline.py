@@ -73,3 +73,32 @@ def test_pipeline_with_disconnected_graph_vs_oracle(tmp_path):
     np.testing.assert_array_equal(res["assign_flat"].reshape(ref["codes"].shape), ref["codes"])
     np.testing.assert_array_equal(res["medoids"], ref["medoid_indices"])
     np.testing.assert_array_equal(res["z_medoid"].numpy(), ref["z_medoid"])
+
+
+def test_bench_prints_one_contract_line():
+    """bench.py on the small c1 workload (the reference's CPU-runnable configuration), CPU baseline included: ONE JSON
+    line on stdout with the driver's fields, the roofline object of the sweep kernel and the cpu_baseline object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GEO_BENCH_CPU_SAMPLE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "latents/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("c1:") and "model" not in d["config"]
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity_selfcheck"]["batched_assign_equals_fused"] is True
