@@ -236,17 +236,27 @@ __global__ __launch_bounds__(256) void running_update_kernel(const float2 *__res
     if ((int)threadIdx.x < nc) { rm = running_mean[c0 + threadIdx.x]; rv = running_var[c0 + threadIdx.x]; }
     for (int g0 = 0; g0 < n_groups; g0 += GB) {
         const int ng = n_groups - g0 < GB ? n_groups - g0 : GB;
-        for (int i = threadIdx.x; i < ng * CH; i += 256) {
-            const int g = i / CH, c = i % CH;
-            blk[i] = c < nc ? stats[(size_t)(g0 + g) * C + c0 + c] : make_float2(0.f, -1.f);
+        float2 ld[GB * CH / 256];                           // all 16 loads of the thread in flight together
+#pragma unroll
+        for (int k = 0; k < GB * CH / 256; ++k) {
+            const int i = k * 256 + threadIdx.x, g = i / CH, c = i % CH;
+            ld[k] = (g < ng && c < nc) ? stats[(size_t)(g0 + g) * C + c0 + c] : make_float2(0.f, -1.f);
         }
+#pragma unroll
+        for (int k = 0; k < GB * CH / 256; ++k) blk[k * 256 + threadIdx.x] = ld[k];
         __syncthreads();
         if ((int)threadIdx.x < nc) {
-            for (int g = 0; g < ng; ++g) {
-                const float2 st = blk[g * CH + threadIdx.x];
-                if (st.y < 0.f) continue;                  // empty or single-element batch
-                rm = (1.0f - m) * rm + m * st.x;
-                rv = (1.0f - m) * rv + m * st.y;
+            for (int g = 0; g < ng; g += 8) {              // 8 LDS reads in flight, then their dependent updates
+                float2 st[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st[j] = blk[(g + j) * CH + threadIdx.x];    // (rows past ng hold the skip mark)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {              // (selects, not branches: the chain is the critical path)
+                    const bool live = st[j].y >= 0.f;      // else: empty or single-element batch (or past the end)
+                    const float nm = (1.0f - m) * rm + m * st[j].x, nv = (1.0f - m) * rv + m * st[j].y;
+                    rm = live ? nm : rm;
+                    rv = live ? nv : rv;
+                }
             }
         }
         __syncthreads();
