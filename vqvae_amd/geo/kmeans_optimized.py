@@ -32,8 +32,15 @@ def _to_device_graph(W) -> DeviceCSR:
 
 # Tuning switches of the chain, read ONCE at import (tests flip them through _KNOBS, bench leaves them alone).
 _KNOBS = {"resident": os.environ.get("GEO_KPP_RESIDENT", "1") != "0",
-          "resident_from": int(os.environ.get("GEO_KPP_RESIDENT_FROM", "32")),
+          "resident_from": int(os.environ.get("GEO_KPP_RESIDENT_FROM", "0")),       # 0: by graph size, see _resident_from
           "log": os.environ.get("GEO_KPP_LOG", "0") == "1"}
+
+
+def _resident_from(n: int) -> int:
+    """First centre the resident workgroup takes over.  Centre t claims about n / t nodes; the workgroup's LDS table holds
+    4096, and below ~1000 nodes per cell it beats the multi-workgroup step kernel (60 000 nodes: 64 gave 21.2 ms for the
+    chain, 32 22.3 ms -- two early cells outgrew the table and were handed back -- 96 21.4 ms)."""
+    return _KNOBS["resident_from"] or max(32, n // 1000)
 
 
 class _Chain:
@@ -167,11 +174,12 @@ def _kpp_chain_device(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
     status = np.zeros(4, dtype=np.int32)
     while it < it1:
         step_mode = finite and not fixed and K <= N
-        resident = step_mode and resident_ok and it >= min(_KNOBS["resident_from"], it1) and it != one_step_at
+        r_from = _resident_from(N)
+        resident = step_mode and resident_ok and it >= min(r_from, it1) and it != one_step_at
         if resident:
             seg_end = it1
         elif step_mode:
-            seg_end = it + 1 if it == one_step_at else (min(it1, _KNOBS["resident_from"]) if resident_ok and it < _KNOBS["resident_from"] else it1)
+            seg_end = it + 1 if it == one_step_at else (min(it1, r_from) if resident_ok and it < r_from else it1)
         else:
             seg_end = min(it1, it + seg)
         t_call = time.perf_counter()
