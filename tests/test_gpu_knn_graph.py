@@ -166,6 +166,30 @@ def test_large_corpus_filter_path_vs_oracle(d, filt):
     assert (idx[:, 0] == np.arange(n)).all() and (np.diff(d2, axis=1) >= 0).all()
 
 
+@pytest.mark.parametrize("filt", [1, 2])
+def test_filter_margins_hold_far_from_the_origin(filt):
+    """Latents shifted by +40 in every coordinate: norms (25 600) dwarf the neighbour distances (~10), so the filter's
+    rounding margin -- relative to |x|^2 + |y|^2, wider for the bf16 scan (1) than for the float32 one (2) -- decides
+    what is kept; the lists must still be the exact ones, and a coordinate scale of 1e3 must not change that either."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    from vqvae_amd import _lib
+    n, kq = 42000, 21
+    for scale, shift in ((1.0, 40.0), (1000.0, 0.0), (1e-3, 0.05)):
+        z = (latents(n, 16, 5) * np.float32(scale) + np.float32(shift)).astype(np.float32)
+        _lib.check(_lib.load().geo_set_option(b"knn_filter", int(filt)), "geo_set_option")
+        try:
+            idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+        finally:
+            _lib.load().geo_set_option(b"knn_filter", 1)
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+        for r0, r1 in ((0, 40), (30000, 30040)):
+            io, do = _oracle_rows(z, kq, 1, r0, r1)
+            np.testing.assert_array_equal(idx[r0:r1], io, err_msg=str((scale, shift)))
+            np.testing.assert_array_equal(d2[r0:r1], do)
+
+
 def test_large_corpus_row_ranges_equal_the_full_search():
     """Query-row shards (the multi-rank layout, parallel.sharded_knn) of a corpus that takes the filter path."""
     import torch
