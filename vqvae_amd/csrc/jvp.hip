@@ -64,10 +64,17 @@ __global__ __launch_bounds__(256) void compose_front_kernel(const float *__restr
         const int px = n / c1, co = n % c1;
         const int ky = (px >> 1) + 1, kx = (px & 1) + 1;
         double s = 0.0;
-        for (int ci = 0; ci < c0; ++ci) {
-            const double m1 = (double)w1[(((size_t)ci * c1 + co) * 4 + ky) * 4 + kx];
-            const double a = k < d ? (double)w_in[(size_t)ci * d + k] : (double)b_in[ci];
-            s = fma(a, m1, s);
+        for (int c8 = 0; c8 < c0; c8 += 8) {               // 16 strided loads in flight, then the fma chain in ci order
+            float m1[8], a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = c8 + j < c0 ? c8 + j : c0 - 1;
+                m1[j] = w1[(((size_t)ci * c1 + co) * 4 + ky) * 4 + kx];
+                a[j] = k < d ? w_in[(size_t)ci * d + k] : b_in[ci];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c8 + j < c0) s = fma((double)a[j], (double)m1[j], s);
         }
         if (k < d) M01[(size_t)k * n1 + n] = (float)s;
         else b01[n] = (float)(s + (double)b1[co]);
