@@ -283,7 +283,7 @@ def main():
         parts = [name for name, on in (("kNN query rows", sharded.get("knn")), ("JVP chunks", sharded.get("jvp")),
                                        ("assignment sources", sharded.get("assign"))) if on]
         parallelism = (f"{world} ranks over {backend}: " + (" + ".join(parts) + " sharded (all-gather merges)" if parts else "nothing sharded")
-                       + "; k-means++ chain replicated")
+                       + f"; k-means++ chain replicated on every rank ({stages_ms.get('kmedoids', 0.0):.1f} ms of the step do not shard)")
     else:
         parallelism = "1 gpu"
     out = {
