@@ -220,6 +220,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON of rank 0: whatever libraries write to file descriptor 1 meanwhile (gloo
+    # announces its connections there) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         log(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -321,7 +326,8 @@ def main():
             full = args.workload in ("c1", "c2") and os.environ.get("GEO_BENCH_CPU_SAMPLE", "0") != "1"
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_baseline(res, z, dec, cfg, full)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
