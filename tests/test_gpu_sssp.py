@@ -126,6 +126,41 @@ def test_long_geodesics_16_source_batches(group, request):
     assert sweeps > 30                                              # long paths really were exercised
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_long_geodesics_in_the_fixed_point_kernel_with_ordered_sources(group, request):
+    """The swiss-roll structure with weights of one binade (seeded formula): ~60-hop geodesics fit 32 bits of weight units,
+    so the fixed-point kernel answers -- and when few pairs moved in the first sweeps (or grouping is forced) it orders the
+    sources along the landmark distances itself and starts over.  Same distances, minima and first-row argmin as the
+    oracle; distances that cannot fit (a few weights scaled by 2^-4: finer units) send the ordered sources to the fp64 kernels."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from oracle.synthetic import formula_weights
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    from vqvae_amd import _lib
+    _lib.check(_lib.load().geo_set_option(b"sssp_group", int(group)), "geo_set_option")
+    request.addfinalizer(lambda: _lib.load().geo_set_option(b"sssp_group", 1))
+    n = 14000
+    W, _ = okn.build_knn_graph(swiss_roll_latents(n, 16, 3), k=10, mode="connectivity", sym="union")
+    W = W.tocsr()
+    rows = np.repeat(np.arange(n), np.diff(W.indptr))
+    W.data = formula_weights(np.minimum(rows, W.indices), np.maximum(rows, W.indices)).astype(np.float32)   # symmetric
+    src = np.random.RandomState(6).choice(n, 96, replace=False)
+    Do = osp.dijkstra_multi_source(W, src)
+    np.testing.assert_array_equal(dijkstra_multi_source(W, src), Do)
+    assert _lib.load().geo_sssp_last_profile(None, None) == 2032
+    G = DeviceCSR.from_scipy(W, device())
+    _, _, dmin, arg, sweeps = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
+    np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+    np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+    assert sweeps > 30
+    Tiny = W.copy()
+    Tiny.data = (Tiny.data * np.where(formula_weights(np.minimum(rows, W.indices), np.maximum(rows, W.indices)) > 1.45,
+                                      np.float32(2.0 ** -4), np.float32(1.0))).astype(np.float32)          # 5 binades: eligible, but 60 hops overflow
+    np.testing.assert_array_equal(dijkstra_multi_source(Tiny, src), osp.dijkstra_multi_source(Tiny, src))
+
+
 def test_errors():
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, distances_between, ensure_valid_graph
     W = line_graph(4)

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -735,6 +736,21 @@ __global__ void gather_f32_kernel(const double *__restrict__ d, const int32_t *_
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = (float)d[at[i]];
 }
 
+// largest finite entry of a non-negative fp64 vector (bit patterns of non-negative doubles order like the doubles)
+__global__ __launch_bounds__(256) void max_finite_kernel(const double *__restrict__ d, int32_t n, unsigned long long *__restrict__ out) {
+    unsigned long long m = 0ull;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(d[i]);
+        if (b < 0x7ff0000000000000ull && b > m) m = b;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 struct MultiWs {
     double *dist;
     int32_t *pred;
@@ -854,7 +870,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         void *stmp = ar.take<char>(sbytes);
         lm_d = ar.take<double>((size_t)n);
         lm_key = ar.take<float>(2 * (size_t)nb * sb);
-        lm_flags = ar.take<int32_t>(4);
+        lm_flags = ar.take<int32_t>(16);                    // [0..3] solve flags, [8..9] the landmark eccentricity (u64)
         wunits = ar.take<uint32_t>((size_t)(nnz > 0 ? nnz : 1));
         wrange = ar.take<uint32_t>(4);
         GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange,
@@ -883,6 +899,51 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         GEO_HIP_CHECK(hipEventCreate(&g_ev0));
         GEO_HIP_CHECK(hipEventCreate(&g_ev1));
     }
+    // ---- order the sources along two landmark distances (see below: "Sources that lie close together ...") ----
+    bool grouped = false;
+    double landmark_ecc = 0.0;
+    auto regroup_sources = [&]() -> int {
+        int32_t lm_sweeps = 0;
+        std::vector<float> ka(n_sources), kb(n_sources);
+        const int gk = geo::grid_for(n_sources, 256, 64);
+        if (int rc = solve_single(indptr, indices, weights, n, host_sources[0], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
+        gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
+        unsigned long long *ecc_dev = reinterpret_cast<unsigned long long *>(lm_flags + 8), ecc_bits = 0ull;   // (8-byte aligned scratch)
+        GEO_HIP_CHECK(hipMemsetAsync(ecc_dev, 0, sizeof(unsigned long long), stream));
+        max_finite_kernel<<<geo::grid_for(n, 256, 1024), 256, 0, stream>>>(lm_d, n, ecc_dev);
+        GEO_HIP_CHECK(hipMemcpyAsync(&ecc_bits, ecc_dev, sizeof(ecc_bits), hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipMemcpyAsync(ka.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        {
+            double e;
+            memcpy(&e, &ecc_bits, sizeof(e));
+            landmark_ecc = e;                                  // farthest node from sources[0] (its component)
+        }
+        int32_t far = 0;
+        float amax = 0.f;
+        for (int32_t i = 0; i < n_sources; ++i)
+            if (std::isfinite(ka[i]) && ka[i] > amax) { amax = ka[i]; far = i; }
+        if (int rc = solve_single(indptr, indices, weights, n, host_sources[far], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
+        gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
+        GEO_HIP_CHECK(hipMemcpyAsync(kb.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        float bmax = 0.f;
+        for (int32_t i = 0; i < n_sources; ++i)
+            if (std::isfinite(kb[i]) && kb[i] > bmax) bmax = kb[i];
+        std::vector<uint64_t> key(n_sources);
+        for (int32_t i = 0; i < n_sources; ++i) {
+            // sources the landmarks cannot reach (other components) sort last
+            const uint32_t qa = std::isfinite(ka[i]) && amax > 0.f ? (uint32_t)(65535.0f * ka[i] / amax) : 65535u;
+            const uint32_t qb = std::isfinite(kb[i]) && bmax > 0.f ? (uint32_t)(65535.0f * kb[i] / bmax) : 65535u;
+            uint64_t m = 0;
+            for (int bit = 15; bit >= 0; --bit) m = (m << 2) | (uint64_t)(((qa >> bit) & 1u) << 1) | ((qb >> bit) & 1u);
+            key[i] = (m << 32) | (uint32_t)i;
+        }
+        std::sort(key.begin(), key.end());
+        for (int32_t i = 0; i < n_sources; ++i) order[i] = (int32_t)(key[i] & 0xffffffffu);
+        grouped = true;
+        return GEO_OK;
+    };
     g_last_sweep_ms = 0.0;
     // ---- exact 32-bit fixed-point solve (32 sources per row) when the weights qualify; see sweep_chunk32u_kernel ----
     if (chunked && n_sources >= 32 && opt.sssp_u32 != 0) {
@@ -911,7 +972,15 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
             row_order_kernel<<<1, 1024, 0, stream>>>(chunk_cnt, n, row_order);
             GEO_LAUNCH_CHECK();
             std::vector<int32_t> hsrc32((size_t)nb32 * 32, -1), hrow32((size_t)nb32 * 32, -1), hf(nb32), hc(2 * (size_t)nb32);
-            for (int32_t i = 0; i < n_sources; ++i) { hsrc32[i] = host_sources[i]; hrow32[i] = i; }
+            int32_t sweeps = 0, sweeps_before = 0;
+            bool done = false, give_up = false;
+            // a long-geodesics graph restarts ONCE with the sources ordered along the landmark distances (as the fp64
+            // solve does): the fixed-point kernel then sweeps rows of 32 neighbouring sources
+            for (int att32 = 0; att32 < 2 && !done && !give_up; ++att32) {
+            bool restart = false;
+            sweeps_before += sweeps;
+            sweeps = 0;
+            for (int32_t i = 0; i < n_sources; ++i) { hsrc32[i] = host_sources[order[i]]; hrow32[i] = order[i]; }
             GEO_HIP_CHECK(hipMemcpyAsync(w.src_pad, hsrc32.data(), hsrc32.size() * 4, hipMemcpyHostToDevice, stream));
             GEO_HIP_CHECK(hipMemcpyAsync(row_of, hrow32.data(), hrow32.size() * 4, hipMemcpyHostToDevice, stream));
             GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, 3 * (size_t)cs * sizeof(int32_t), stream));
@@ -922,13 +991,15 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                 w.src_pad, n_sources, n, 32, words, indptr, indices, bits + 2 * (size_t)nb32 * words);
             GEO_LAUNCH_CHECK();
             const int gs32 = nb32 < 8 ? nb32 : 8, groups32 = (nb32 + gs32 - 1) / gs32;
-            const int cap32 = 65536 / (gs32 * groups32);
+            const int cap32_all = 65536 / (gs32 * groups32);
+            // (grouped solves: many sweeps that touch few rows -- a smaller grid and the flagged-row body throughout)
+            const int cap32 = (grouped && cap32_all > opt.sssp_grouped_cap) ? opt.sssp_grouped_cap : cap32_all;
+            const int sdiv32 = grouped && opt.sssp_sparse_div <= 0 ? 1 : sparse_div;
+            const int mdiv32 = grouped && opt.sssp_map_div <= 0 ? 1 : map_div;
             const int per_batch = geo::grid_for(n, 8, cap32 > 0 ? cap32 : 1);     // 8 row slots per block
             const unsigned grid = (unsigned)per_batch * (unsigned)gs32 * (unsigned)groups32;
-            int32_t sweeps = 0;
-            bool done = false, give_up = false;
             int group_len = SWEEP_GROUP;
-            while (!done && !give_up) {
+            while (!done && !give_up && !restart) {
                 int last_cur = 0;
                 GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
                 for (int g = 0; g < group_len; ++g, ++sweeps) {
@@ -937,8 +1008,8 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                     if (sweeps > 0) GEO_HIP_CHECK(hipMemsetAsync(bcur, 0, (size_t)nb32 * words * 4, stream));
                     sweep_chunk32u_kernel<<<grid, 256, 0, stream>>>(indptr, indices, wunits, n, nb32, row_order,
                                                                   per_batch, gs32, dist32, w.flags, counts, bprev,
-                                                                  bcur, words, prev, cur, next, sweeps == 0, act_mode, sparse_div,
-                                                                  map_div, (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4,
+                                                                  bcur, words, prev, cur, next, sweeps == 0, act_mode, sdiv32,
+                                                                  mdiv32, (sweeps + 2) % 4, (sweeps + 3) % 4, sweeps % 4,
                                                                   (sweeps + 1) % 4, cs);
                     GEO_LAUNCH_CHECK();
                     if (opt.sssp_trace) {                              // experiment: sampled improvement counts per sweep
@@ -961,15 +1032,23 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                 g_last_sweep_ms += ms;
                 done = true;
                 for (int32_t b = 0; b < nb32; ++b) done = done && (hf[b] == 0);
-                if (!done && sweeps == SWEEP_GROUP && group_mode != 0) {
-                    // long geodesics (few pairs moved so far): the fp64 path below regroups the sources and takes over
+                if (!done && att32 == 0 && !grouped && sweeps == SWEEP_GROUP && group_mode != 0) {
+                    // long geodesics (few pairs moved so far): order the sources, start over
                     double moved = 0.0;
                     for (int32_t b = 0; b < 2 * nb32; ++b) moved += 16.0 * (hc[b] < 0 ? -hc[b] : hc[b]);
-                    give_up = group_mode == 2 || moved < 0.25 * (double)nb32 * n * 32;
+                    if (group_mode == 2 || moved < 0.25 * (double)nb32 * n * 32) {
+                        if (int rc = regroup_sources()) return rc;
+                        restart = true;
+                        // some node is landmark_ecc away from sources[0]: if that alone does not fit 32 bits of units the
+                        // fixed-point solve would only find out at its end -- the fp64 kernels take the (ordered) sources now
+                        if (landmark_ecc / unit >= 4294967294.0) give_up = true;
+                    }
                 }
                 if (!done && sweeps > (int64_t)n + 2) give_up = true;
                 if (sweeps >= 16 && group_len < 16) group_len *= 2;
             }
+            }                                                  // att32
+            sweeps += sweeps_before;
             if (done) {
                 int32_t ovf = 0;
                 GEO_HIP_CHECK(hipMemsetAsync(w.flags, 0, sizeof(int32_t), stream));
@@ -1003,7 +1082,6 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                                    argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }
     int32_t total_sweeps = 0;
-    bool grouped = false;
     // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
     // sources moved a neighbour, so with 16 scattered sources every row is re-evaluated as each of 16 fronts
     // passes (and their corrections cascade), with 16 neighbouring sources the fronts pass as one.  On graphs
@@ -1105,38 +1183,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         total_sweeps += sweeps;
         if (done) break;
         // ---- order the sources along two landmark distances, then start over ----
-        {
-            int32_t lm_sweeps = 0;
-            std::vector<float> ka(n_sources), kb(n_sources);
-            const int gk = geo::grid_for(n_sources, 256, 64);
-            if (int rc = solve_single(indptr, indices, weights, n, host_sources[0], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
-            gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
-            GEO_HIP_CHECK(hipMemcpyAsync(ka.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
-            GEO_HIP_CHECK(hipStreamSynchronize(stream));
-            int32_t far = 0;
-            float amax = 0.f;
-            for (int32_t i = 0; i < n_sources; ++i)
-                if (std::isfinite(ka[i]) && ka[i] > amax) { amax = ka[i]; far = i; }
-            if (int rc = solve_single(indptr, indices, weights, n, host_sources[far], lm_d, lm_flags, 16, stream, &lm_sweeps)) return rc;
-            gather_f32_kernel<<<gk, 256, 0, stream>>>(lm_d, sources, n_sources, lm_key);
-            GEO_HIP_CHECK(hipMemcpyAsync(kb.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
-            GEO_HIP_CHECK(hipStreamSynchronize(stream));
-            float bmax = 0.f;
-            for (int32_t i = 0; i < n_sources; ++i)
-                if (std::isfinite(kb[i]) && kb[i] > bmax) bmax = kb[i];
-            std::vector<uint64_t> key(n_sources);
-            for (int32_t i = 0; i < n_sources; ++i) {
-                // sources the landmarks cannot reach (other components) sort last
-                const uint32_t qa = std::isfinite(ka[i]) && amax > 0.f ? (uint32_t)(65535.0f * ka[i] / amax) : 65535u;
-                const uint32_t qb = std::isfinite(kb[i]) && bmax > 0.f ? (uint32_t)(65535.0f * kb[i] / bmax) : 65535u;
-                uint64_t m = 0;
-                for (int bit = 15; bit >= 0; --bit) m = (m << 2) | (uint64_t)(((qa >> bit) & 1u) << 1) | ((qb >> bit) & 1u);
-                key[i] = (m << 32) | (uint32_t)i;
-            }
-            std::sort(key.begin(), key.end());
-            for (int32_t i = 0; i < n_sources; ++i) order[i] = (int32_t)(key[i] & 0xffffffffu);
-            grouped = true;
-        }
+        if (int rc = regroup_sources()) return rc;
     }
     const int32_t sweeps = total_sweeps;
     if (sweeps_out) *sweeps_out = sweeps;
