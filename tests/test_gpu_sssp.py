@@ -161,6 +161,41 @@ def test_long_geodesics_in_the_fixed_point_kernel_with_ordered_sources(group, re
     np.testing.assert_array_equal(dijkstra_multi_source(Tiny, src), osp.dijkstra_multi_source(Tiny, src))
 
 
+def test_seeded_sweep_over_graphs_sources_and_weight_ranges():
+    """Twelve seeded combinations of structure (Gaussian cloud / swiss roll), size, degree, number of sources and weight
+    range (one binade ... eleven): whichever kernels the dispatch picks (fixed point with or without ordered sources,
+    16- or 64-source fp64 batches, small-graph kernel), D, the column minimum and the first-row argmin equal the oracle's."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from oracle.synthetic import formula_weights
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    from vqvae_amd import _lib
+    rs = np.random.RandomState(2024)
+    seen = set()
+    cases = [(3000, 6, 17, False, 0), (9000, 4, 33, True, 1), (15000, 10, 70, False, 2), (26000, 6, 130, True, 2),
+             (40000, 10, 33, False, 1), (15000, 4, 70, True, 1), (26000, 10, 17, False, 0), (9000, 10, 130, False, 2),
+             (40000, 4, 33, True, 0), (3000, 4, 130, True, 2), (15000, 6, 33, False, 0), (26000, 10, 70, True, 1)]
+    for case, (n, k, S, roll, mode) in enumerate(cases):
+        z = swiss_roll_latents(n, 8, case) if roll else latents(n, 8, case)
+        W, _ = okn.build_knn_graph(z, k=k, mode="distance", sym="union")
+        W = W.tocsr()
+        if mode:                                                        # seeded weights: one binade, or stretched over many
+            rows = np.repeat(np.arange(n), np.diff(W.indptr))
+            f = formula_weights(rows, W.indices).astype(np.float64)
+            W.data = (f if mode == 1 else f * np.exp2(np.floor((f - 0.5) * 11.0))).astype(np.float32)
+        src = rs.choice(n, S, replace=False)
+        Do = osp.dijkstra_multi_source(W, src)
+        np.testing.assert_array_equal(dijkstra_multi_source(W, src), Do, err_msg=str((case, n, k, S, roll, mode)))
+        seen.add(int(_lib.load().geo_sssp_last_profile(None, None)))
+        G = DeviceCSR.from_scipy(W, device())
+        _, _, dmin, arg, _ = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
+        np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+        np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+    assert len(seen) >= 3, seen                                         # several kernels really answered
+
+
 def test_errors():
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, distances_between, ensure_valid_graph
     W = line_graph(4)
