@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void pack_back_bf16_kernel(const float *__rest
 }
 
 template <int NT, bool GN>
-__global__ __launch_bounds__(256) void back_mfma_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
+__global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
                                                        const NormConst *__restrict__ consts2, int consts_per_group,
                                                        int tiles_per_group, int co_n, int s_out,
                                                        const unsigned short *__restrict__ W3b,
