@@ -189,3 +189,34 @@ def test_train_mode_jvp_updates_batchnorm_running_statistics(golden, bs):
     before = {k: v.clone() for k, v in dec.state_dict().items()}
     edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), batch_size=bs)
     assert all(torch.equal(v, dec.state_dict()[k]) for k, v in before.items())
+
+
+@pytest.mark.parametrize("d,norm", [(64, "none"), (24, "none"), (40, "batch"), (64, "group")])
+def test_wide_latents_matrix_core_front_equals_the_vector_kernel(d, norm, request):
+    """d > 16: the first layer runs on the float32 matrix cores, whose accumulation is the same k-ordered fmaf chain as
+    the vector kernel's -- identical lengths without a norm layer (also for a padded latent width), within rounding of
+    the fp64 batch statistics' summation order with one; both within the usual gate of the fp64 closed form."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    sd = om.make_decoder_state(11, d, 3, norm_type=norm)
+    dec = SpatialDecoder(3, (256, 128, 64), d, 32, norm)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(device()).train()
+    r = np.random.RandomState(d)
+    zs = r.randn(1500, d).astype(np.float32)
+    ze = (zs + 0.3 * r.randn(1500, d)).astype(np.float32)
+    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_front_valu", 0))
+    out = {}
+    for valu in (0, 1):
+        _lib.check(_lib.load().geo_set_option(b"jvp_front_valu", valu), "geo_set_option")
+        out[valu] = edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), 512).cpu().numpy()
+    if norm == "none":
+        np.testing.assert_array_equal(out[0], out[1])
+    else:
+        np.testing.assert_allclose(out[0], out[1], rtol=2e-6)
+    ref64 = om.edge_lengths(sd, norm, 32, zs, ze, 512, True, dtype=torch.float64).numpy()
+    rel = np.abs(out[0] - ref64) / np.abs(ref64)
+    assert (rel <= TOL).mean() >= 0.999, (rel <= TOL).mean()

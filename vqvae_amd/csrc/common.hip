@@ -22,6 +22,7 @@ const OptionName kOptionNames[] = {
     {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},
     {"jvp_mid", "GEO_JVP_MID", &Options::jvp_mid},
     {"jvp_back_valu", "GEO_JVP_BACK_VALU", &Options::jvp_back_valu},
+    {"jvp_front_valu", "GEO_JVP_FRONT_VALU", &Options::jvp_front_valu},
 };
 Options from_environment() {
     Options o;

@@ -149,6 +149,11 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
         dz[s][k] = b - a;
         if (k == 0) valid_s[s] = ok ? 1 : 0;
     }
+    for (int i = threadIdx.x; i < TS * (DMAX - d); i += 256) {      // padded latent columns: zeros, not stale LDS
+        const int s = i / (DMAX - d), k = d + i % (DMAX - d);
+        zp[s][k] = 0.f;
+        dz[s][k] = 0.f;
+    }
     __syncthreads();
     const size_t slot0 = (size_t)tile * TS;
     for (int n = threadIdx.x; n < n1; n += 256) {
@@ -171,6 +176,90 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
             }
         }
         if (want_stats) { ps[n][0] = sx; ps[n][1] = sxx; ps[n][2] = st; ps[n][3] = sxt; }
+    }
+    if (want_stats) {                                       // the four pixels of a channel, in pixel order: [tile][c1][4]
+        __syncthreads();
+        const int c1 = n1 / 4;
+        for (int c = threadIdx.x; c < c1; c += 256) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) { a0 += ps[px * c1 + c][0]; a1 += ps[px * c1 + c][1]; a2 += ps[px * c1 + c][2]; a3 += ps[px * c1 + c][3]; }
+            double *p = partial + ((size_t)tile * c1 + c) * 4;
+            p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
+        }
+    }
+}
+
+// The same product on the float32 matrix cores for wide latents (d > 16: the VALU kernel spends 2 x d FMAs per value,
+// 7.3 ms of the 50 000 x 64 configuration's step).  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain into the accumulator,
+// which starts at the bias: bit for bit the chain of front_kernel (x = bias; x = fmaf(z_k, m_k, x), k ascending).
+// One wave = 32 samples x 32 columns at a time (primal and tangent accumulators), a workgroup = 4 waves over the n1 / 32
+// column tiles; A (latents, differences) from LDS, B (M01) from L2; statistics from the accumulators (lane = column).
+template <int DMAX>
+__global__ __launch_bounds__(256) void front_mfma_kernel(const float *__restrict__ z, const int32_t *__restrict__ src,
+                                                        const int32_t *__restrict__ dst, const float *__restrict__ z_start,
+                                                        const float *__restrict__ z_end, int64_t e_base, int64_t n_edges,
+                                                        int batch, int tiles_per_group, int d, int n1,
+                                                        const float *__restrict__ M01, const float *__restrict__ b01,
+                                                        float *__restrict__ pre, float *__restrict__ tpre,
+                                                        double *__restrict__ partial, int want_stats) {
+    __shared__ float zp[TS][DMAX + 1];
+    __shared__ float dz[TS][DMAX + 1];
+    __shared__ int valid_s[TS];
+    __shared__ double ps[FRONT_MAX_N1][4];
+    const int tile = blockIdx.x;
+    const int group = tile / tiles_per_group, tg = tile % tiles_per_group;
+    const int chunk = group >> 1, side = group & 1;
+    for (int i = threadIdx.x; i < TS * DMAX; i += 256) {
+        const int s = i / DMAX, k = i % DMAX;
+        const int within = tg * TS + s;
+        const int64_t e = e_base + (int64_t)chunk * batch + within;
+        float a = 0.f, b = 0.f;
+        const bool ok = within < batch && e < n_edges;
+        if (ok && k < d) {
+            if (src) {
+                a = z[(int64_t)src[e] * d + k];
+                b = z[(int64_t)dst[e] * d + k];
+            } else {
+                a = z_start[e * d + k];
+                b = z_end[e * d + k];
+            }
+        }
+        zp[s][k] = side == 0 ? a : b;
+        dz[s][k] = b - a;
+        if (k == 0) valid_s[s] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const size_t slot0 = (size_t)tile * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int ct = wave; ct * 32 < n1; ct += 4) {
+        const int n = ct * 32 + r;                              // this lane's column
+        f32x16 accp, acct;
+        const float bias = b01[n];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { accp[q] = bias; acct[q] = 0.f; }
+#pragma unroll 8
+        for (int i = 0; i < DMAX / 2; ++i) {
+            const int k = 2 * i + h;
+            const float bm = k < d ? M01[(size_t)k * n1 + n] : 0.f;
+            accp = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[r][k], bm, accp, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[r][k], bm, acct, 0, 0, 0);
+        }
+        double sx = 0, sxx = 0, st = 0, sxt = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float x = accp[q], t = acct[q];
+            pre[(slot0 + row) * n1 + n] = x;
+            tpre[(slot0 + row) * n1 + n] = t;
+            if (valid_s[row]) { sx += x; sxx += (double)x * x; st += t; sxt += (double)x * t; }
+        }
+        if (want_stats) {
+            sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+            st += __shfl_xor(st, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+            if (lane < 32) { ps[n][0] = sx; ps[n][1] = sxx; ps[n][2] = st; ps[n][3] = sxt; }
+        }
     }
     if (want_stats) {                                       // the four pixels of a channel, in pixel order: [tile][c1][4]
         __syncthreads();
@@ -1142,9 +1231,15 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     front_kernel<DM><<<(unsigned)p_tiles, 256, 0, stream>>>(z, src, dst, z_start, z_end, e_base, n_edges, batch,    \
                                                             pl.tiles_per_group, s.d, s.n1, M01, b01, pre1, tpre1,   \
                                                             part1, batch_stats ? 1 : 0)
+#define GEO_FRONT_MFMA(DM)                                                                                         \
+    front_mfma_kernel<DM><<<(unsigned)p_tiles, 256, 0, stream>>>(z, src, dst, z_start, z_end, e_base, n_edges, batch, \
+                                                                 pl.tiles_per_group, s.d, s.n1, M01, b01, pre1,       \
+                                                                 tpre1, part1, batch_stats ? 1 : 0)
+        const bool front_mfma = s.d > 16 && s.n1 % 32 == 0 && geo::options().jvp_front_valu == 0;
         if (s.d <= 16) GEO_FRONT(16);
-        else if (s.d <= 32) GEO_FRONT(32);
-        else GEO_FRONT(64);
+        else if (s.d <= 32) { if (front_mfma) GEO_FRONT_MFMA(32); else GEO_FRONT(32); }
+        else { if (front_mfma) GEO_FRONT_MFMA(64); else GEO_FRONT(64); }
+#undef GEO_FRONT_MFMA
 #undef GEO_FRONT
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
