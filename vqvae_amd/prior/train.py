@@ -4,12 +4,15 @@ is single-process).  One process per GPU, `torch.distributed` over RCCL ("nccl" 
 Every rank walks the SAME sequence of global batches (same seed -> same shuffling) and takes a contiguous slice of each
 one.  Its loss is the SUM of its samples' token losses divided by the GLOBAL token count, so the all-reduced (summed)
 gradients are exactly the gradients of the reference's mean loss over the global batch: N ranks reproduce the
-single-process run up to float summation order.  All gradients live in ONE flat buffer (each p.grad is a view of it),
-reduced with a single all-reduce per step: 3.3 M parameters = 13 MB, far below what a ring over xGMI needs to be
-bandwidth-bound, so bucketing or overlap with backward would buy nothing here.
+single-process run up to float summation order -- for dropout = 0.  With dropout > 0 a rank draws the masks of ITS
+slice from its own generator stream (`seed_dropout_stream`), so an N-rank run is a valid run of the same training
+procedure but not a replay of the single-process one (whose masks depend on the batch being processed whole).
+The model keeps all weights in one arena (vqvae_amd/prior/transformer.py), so all gradients are ONE flat buffer
+(`model.arena.grad`), reduced with a single all-reduce per step: 3.3 M parameters = 13 MB, far below what a ring over xGMI
+needs to be bandwidth-bound, so bucketing or overlap with backward would buy nothing here.
 """
 from pathlib import Path
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -21,25 +24,18 @@ from ..parallel import block_range, world_info
 from .transformer import Transformer
 
 
-class FlatGradients:
-    """One contiguous buffer holding every parameter's gradient; all_reduce() sums it over the ranks in one collective."""
+def _reduce_sum(t: torch.Tensor, group=None) -> None:
+    if world_info(group)[1] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
-    def __init__(self, params: List[torch.nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
-        first = self.params[0]
-        self.flat = torch.zeros(total, dtype=first.dtype, device=first.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce(self, group=None):
-        if world_info(group)[1] > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+def seed_dropout_stream(seed: int, rank: int, device: torch.device) -> None:
+    """Give this rank its own dropout stream (call AFTER the model is built and the loaders hold their own generator):
+    ranks must not repeat rank 0's masks on their slices."""
+    if device.type == "cuda":
+        torch.cuda.manual_seed(int(seed) + 7919 * (rank + 1))
+    else:
+        torch.manual_seed(int(seed) + 7919 * (rank + 1))
 
 
 def _batch_to(batch, device, lo, hi, with_labels):
@@ -57,7 +53,9 @@ def train_prior(model: Transformer, train_loader, val_loader, *, epochs: int, lr
     rank, world = world_info(group)
     optimizer = AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
     scheduler = CosineAnnealingLR(optimizer, T_max=int(epochs))
-    grads = FlatGradients(list(model.parameters()))
+    if model.arena.grad is None:
+        model.arena.grad = torch.zeros_like(model.arena)          # the one gradient buffer: zeroed, reduced, consumed in place
+    grads = model.arena.grad
     history = {"train_loss": [], "val_loss": []}
     best = float("inf")
     step = 0
@@ -67,17 +65,16 @@ def train_prior(model: Transformer, train_loader, val_loader, *, epochs: int, lr
             B = batch[0].shape[0]
             lo, hi = block_range(B, rank, world)
             x, y, labels = _batch_to(batch, device, lo, hi, model.num_classes > 0)
-            grads.zero()
+            grads.zero_()
             loss_sum = torch.zeros((), device=device)
             if hi > lo:
                 logits = model(x, y=labels)
-                loss_sum = F.cross_entropy(logits.view(-1, logits.size(-1)), y.view(-1), reduction="sum")
+                loss_sum = F.cross_entropy(logits.reshape(-1, logits.size(-1)), y.reshape(-1), reduction="sum")
                 (loss_sum / (B * y.shape[1])).backward()
-            grads.all_reduce(group)
+            _reduce_sum(grads, group)
             optimizer.step()
             total = loss_sum.detach().clone()
-            if world > 1:
-                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            _reduce_sum(total, group)
             loss = float(total) / (B * batch[1].shape[1])
             history["train_loss"].append(loss)
             if on_step is not None:
@@ -90,7 +87,7 @@ def train_prior(model: Transformer, train_loader, val_loader, *, epochs: int, lr
             for batch in val_loader:                 # identical on every rank (tiny model): no collective needed
                 x, y, labels = _batch_to(batch, device, 0, batch[0].shape[0], model.num_classes > 0)
                 logits = model(x, y=labels)
-                val += F.cross_entropy(logits.view(-1, logits.size(-1)), y.view(-1)).item()
+                val += F.cross_entropy(logits.reshape(-1, logits.size(-1)), y.reshape(-1)).item()
                 n_batches += 1
         val /= max(1, n_batches)
         history["val_loss"].append(val)

@@ -16,7 +16,7 @@ import torch.distributed as dist
 import yaml
 
 from ..prior.codes_dataset import get_code_loaders
-from ..prior.train import train_prior
+from ..prior.train import seed_dropout_stream, train_prior
 from ..prior.transformer import Transformer
 
 
@@ -46,11 +46,19 @@ def main(config_path: str):
             dist.init_process_group("gloo")
     set_seed(cfg["system"]["seed"])          # every rank: same initial weights, same shuffling
     data_cfg, model_cfg, train_cfg = cfg["data"], cfg["model"], cfg["training"]
+    # world > 1: the shuffling gets a generator of its own (seeded identically on every rank), so that the per-rank
+    # dropout streams seeded below cannot pull the ranks' batch orders apart
+    shuffler = None
+    if world > 1:
+        shuffler = torch.Generator()
+        shuffler.manual_seed(int(cfg["system"]["seed"]))
     train_loader, val_loader = get_code_loaders(
         codes_path=data_cfg["codes_path"], labels_path=data_cfg.get("labels_path"), batch_size=data_cfg["batch_size"],
         num_workers=data_cfg["num_workers"], vanilla_vae=data_cfg.get("vanilla_vae", False),
-        num_tokens=model_cfg.get("num_tokens"))
+        num_tokens=model_cfg.get("num_tokens"), device=device, generator=shuffler)
     model = Transformer(**model_cfg).to(device)
+    if world > 1:
+        seed_dropout_stream(cfg["system"]["seed"], dist.get_rank(), device)
     ckpt_dir = Path(cfg["out"]["dir"]) / "checkpoints"
     if not dist.is_initialized() or dist.get_rank() == 0:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
