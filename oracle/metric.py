@@ -147,11 +147,16 @@ def _dense_maps(sd: Mapping, output_image_size: int, dtype):
 
 
 def edge_lengths_dense(sd: Mapping, output_image_size: int, z_start, z_end, batch_size: int = 512,
-                       dtype=torch.float64, device: str = "cpu") -> torch.Tensor:
+                       dtype=torch.float64, device: str = "cpu", with_conditioning: bool = False):
     """The same closed form as edge_lengths(norm_type="batch", training=True) with every layer written as a dense
     matrix product over whole stacks of chunks (the decoder sees a 1x1 latent image, so each transposed convolution
     is a small matrix): identical in exact arithmetic, fp64 rounding differs at 1e-16.  This is what makes the fp64
-    check of EVERY BatchNorm chunk of a full-size run affordable (tests tie it to edge_lengths on sample chunks)."""
+    check of EVERY BatchNorm chunk of a full-size run affordable (tests tie it to edge_lengths on sample chunks).
+    with_conditioning=True also returns a (chunks, 2) array: column 0 = R, the maximum over (endpoint side, BatchNorm
+    layer, channel) of |batch mean| / batch std of the layer's input (x - mean cancels log2(R) leading bits); column 1 =
+    the smallest |pre-activation| entering a ReLU anywhere in the chunk.  A pre-activation within float32 rounding reach
+    of zero makes the ReLU mask of that sample implementation-dependent, and in train mode the flipped tangent enters
+    the NEXT layer's batch means of t and of xhat*t, i.e. it moves every edge of the chunk, not only its own."""
     global _DEVICE
     prev, _DEVICE = _DEVICE, device
     try:
@@ -166,9 +171,13 @@ def edge_lengths_dense(sd: Mapping, output_image_size: int, z_start, z_end, batc
             full = (E // batch_size) * batch_size
             stack = 64 * batch_size                                  # chunks processed together
 
+            cond = []
+
             def run(zs_, ze_, nb, bs):                               # nb chunks of bs edges
                 delta = ze_ - zs_
                 res = 0.0
+                worst = torch.zeros(nb, dtype=dtype, device=device)
+                near0 = torch.full((nb,), float("inf"), dtype=dtype, device=device)
                 for z0 in (zs_, ze_):
                     x = z0 @ w_in.t() + b_in                         # (nb*bs, c0)
                     t = delta @ w_in.t()
@@ -184,14 +193,17 @@ def edge_lengths_dense(sd: Mapping, output_image_size: int, z_start, z_end, batc
                         mu = x.mean(dim=(1, 3), keepdim=True)
                         var = ((x - mu) ** 2).mean(dim=(1, 3), keepdim=True)
                         inv = 1.0 / torch.sqrt(var + BN_EPS)
+                        worst = torch.maximum(worst, (mu.abs() * inv).amax(dim=(1, 2, 3)))
                         xhat = (x - mu) * inv
                         that = inv * (t - t.mean(dim=(1, 3), keepdim=True) - xhat * (xhat * t).mean(dim=(1, 3), keepdim=True))
                         x = xhat * gamma + beta
+                        near0 = torch.minimum(near0, x.abs().amin(dim=(1, 2, 3)))
                         t = (that * gamma) * (x > 0).to(dtype)
                         x = torch.relu(x)
                         x, t = x.reshape(nb * bs, -1), t.reshape(nb * bs, -1)
                     sg = torch.sigmoid(x)
                     res = res + 0.5 * torch.linalg.vector_norm((t * sg * (1.0 - sg)).reshape(nb * bs, -1), dim=1)
+                cond.append(torch.stack([worst, near0], dim=1))
                 return res
 
             for lo in range(0, full, stack):
@@ -199,6 +211,8 @@ def edge_lengths_dense(sd: Mapping, output_image_size: int, z_start, z_end, batc
                 out[lo:hi] = run(zs[lo:hi], ze[lo:hi], (hi - lo) // batch_size, batch_size)
             if full < E:
                 out[full:] = run(zs[full:], ze[full:], 1, E - full)
+            if with_conditioning:
+                return out.to("cpu", torch.float32), torch.cat(cond).to("cpu", torch.float64)
             return out.to("cpu", torch.float32)
     finally:
         _DEVICE = prev

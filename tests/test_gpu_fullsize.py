@@ -19,6 +19,14 @@ pytestmark = pytest.mark.gpu
 N, D, KNN, KMED = 60000, 16, 20, 512
 TOL = 1e-5                       # edge lengths within 1e-5 relative ...
 GATE = 0.999                     # ... for >= 99.9 % of the edges
+# Which chunks may miss the 1e-5 gate is decided by a CRITERION, not by index ("... or flagged ReLU-boundary
+# (|pre-activation| < 1e-6)").  A pre-activation within float32 rounding reach of zero makes that sample's ReLU mask
+# implementation-dependent (any two float32 evaluations, the reference's included, may disagree with fp64 there), and in
+# train mode the flipped tangent enters the next layer's batch means, so it can move EVERY edge of its chunk.  Measured on
+# the CPU with the float32 closed form at C2 (1 848 chunks): all 1 323 edges beyond 1e-5 of fp64 sit in chunks whose
+# smallest |pre-activation| is below 1e-6; the chunks above 3e-6 have max error 1.2e-6.  |batch mean| / batch std, the
+# suspect named in round 2, is at most 0.95 in every chunk: BatchNorm conditioning is NOT the cause (recorded as R).
+NEAR0 = 1e-6
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -93,26 +101,42 @@ def _all_chunks_vs_fp64(ctx, name):
     """EVERY BatchNorm chunk against the fp64 closed form (oracle/metric.py's dense-matrix statement of it, run in fp64
     torch on the GPU and tied to the layer-by-layer CPU form on three chunks); returns the per-edge relative errors."""
     from oracle import metric as om
+    if "_vs_fp64" in ctx:
+        return ctx["_vs_fp64"]
     src, dst = (t.cpu().numpy() for t in ctx["res"]["edges"])
     L = ctx["res"]["edge_lengths"].cpu().numpy()
     assert L.shape == src.shape and np.isfinite(L).all() and (L > 0).all()
     assert (src < dst).all() and (np.diff(src) >= 0).all()       # row-major upper triangle
     zs, ze = ctx["z_h"][src], ctx["z_h"][dst]
-    ref64 = om.edge_lengths_dense(ctx["sd"], ctx["size"], zs, ze, batch_size=512, dtype=torch.float64,
-                                  device="cuda").numpy()
+    ref64, cond = om.edge_lengths_dense(ctx["sd"], ctx["size"], zs, ze, batch_size=512, dtype=torch.float64,
+                                        device="cuda", with_conditioning=True)
+    ref64, R, near0 = ref64.numpy(), cond.numpy()[:, 0], cond.numpy()[:, 1]
     n_chunks = (len(src) + 511) // 512
+    assert len(R) == n_chunks
     for c in (0, min(917, n_chunks - 2), n_chunks - 1):          # the checker itself: dense GPU fp64 == conv CPU fp64
         sl = slice(c * 512, min((c + 1) * 512, len(src)))
         cpu64 = om.edge_lengths(ctx["sd"], "batch", ctx["size"], zs[sl], ze[sl], batch_size=512, training=True,
                                 dtype=torch.float64).numpy()
         np.testing.assert_allclose(ref64[sl], cpu64, rtol=2e-6)  # both are f32-rounded fp64 results
     rel = np.abs(L - ref64) / ref64
-    worst_chunk = max(np.mean(rel[c * 512:(c + 1) * 512] > TOL) for c in range(n_chunks))
+    over_per_chunk = np.array([np.mean(rel[c * 512:(c + 1) * 512] > TOL) for c in range(n_chunks)])
+    flagged = near0 < NEAR0                                          # a ReLU-boundary sample somewhere in the chunk
+    clear_edges = ~np.repeat(flagged, 512)[:len(rel)]
     _record(f"{name}_jvp_vs_fp64", {"edges": int(len(L)), "chunks": int(n_chunks), "edges_over_1e-5": int((rel > TOL).sum()),
                                     "frac_within": float(np.mean(rel <= TOL)), "p99": float(np.quantile(rel, 0.99)),
-                                    "max_rel": float(rel.max()), "worst_chunk_frac_over": float(worst_chunk)})
+                                    "max_rel": float(rel.max()), "worst_chunk_frac_over": float(over_per_chunk.max()),
+                                    "near0_threshold": NEAR0, "boundary_flagged_chunks": int(flagged.sum()),
+                                    "chunks_with_an_edge_over": int((over_per_chunk > 0).sum()),
+                                    "chunks_with_an_edge_over_not_flagged": int(((over_per_chunk > 0) & ~flagged).sum()),
+                                    "edges_over_1e-5_in_unflagged_chunks": int((rel[clear_edges] > TOL).sum()),
+                                    "max_rel_in_unflagged_chunks": float(rel[clear_edges].max()),
+                                    "frac_within_flagged_chunks": float(np.mean(rel[~clear_edges] <= TOL)),
+                                    "R_max_mean_over_std": float(R.max()), "R_median": float(np.median(R))})
     assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
+    assert np.mean(rel[clear_edges] <= TOL) >= 0.9999               # chunks without a boundary sample: (almost) every edge
+    assert (~flagged).sum() >= 64
     assert np.quantile(rel, 0.99) < 2e-6
+    ctx["_vs_fp64"] = (rel, ref64)
     return rel, ref64
 
 
@@ -201,6 +225,143 @@ def test_c2_kmedoids_vs_reference_on_formula_weights(c2, golden):
     assert qe == float(g["qe"])
 
 
+def _graph_with_reference_lengths(c2, golden):
+    """The reference CLI's OWN graph at C2: its structure (= ours, sha256-checked) carrying ITS float32 edge lengths
+    (tests/golden/c2_cli_lengths.npz: all 946 059, row-major upper triangle = the JVP chunk order)."""
+    from oracle import synthetic as syn
+    from vqvae_amd.geo.knn_graph_optimized import reweight_device, upper_edges_device
+    g, gl = golden("c2_cli"), golden("c2_cli_lengths")
+    G = c2["res"]["W_lcc"]
+    assert G.n == N                                              # one component: LCC-local = global indices
+    W = G.to_scipy()
+    np.testing.assert_array_equal(syn.digest(W.indptr.astype(np.int32)), g["indptr_sha256"])
+    np.testing.assert_array_equal(syn.digest(W.indices.astype(np.int32)), g["indices_sha256"])
+    L = gl["lengths"]
+    assert L.dtype == np.float32 and len(L) == int(g["meta"][6])
+    np.testing.assert_array_equal(syn.digest(L), gl["lengths_sha256"])
+    _, _, entry_edge = upper_edges_device(G)
+    return reweight_device(G, entry_edge, torch.from_numpy(L).to(c2["dev"])), L
+
+
+def test_c2_kmedoids_on_reference_jvp_weights_gives_reference_codes(c2, golden):
+    """The stage-wise check at the headline size on the reference's own numbers: reference structure + reference JVP
+    edge lengths -> fit_kmedoids_optimized(K=512, seed=42) on the MI355X must return the reference CLI's
+    medoid_indices and EVERY entry of its codes.npy (src/scripts/build_codebook.py:70-103)."""
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
+    g = golden("c2_cli")
+    Gref, _ = _graph_with_reference_lengths(c2, golden)
+    med, assign, qe = fit_kmedoids_optimized(Gref, K=KMED, init="kpp", seed=42)
+    np.testing.assert_array_equal(med, g["medoid_indices"])
+    np.testing.assert_array_equal(assign, g["codes"].astype(np.int64).reshape(-1))
+    assert np.isfinite(qe) and qe > 0
+
+
+def test_c2_all_reference_edge_lengths_vs_gpu(c2, golden):
+    """Every one of the reference CLI's 946 059 float32 edge lengths against the HIP JVP (the round-2 fixture held
+    every 61st chunk).  Gate on the edges where the reference itself is within 1e-5 of the fp64 closed form."""
+    _, ref64 = _all_chunks_vs_fp64(c2, "c2")
+    _, Lref = _graph_with_reference_lengths(c2, golden)
+    L = c2["res"]["edge_lengths"].cpu().numpy()
+    rel = np.abs(L - Lref) / Lref
+    ref_ok = np.abs(Lref - ref64) / ref64 <= TOL
+    _record("c2_jvp_vs_reference_all", {"edges": int(len(L)), "frac_within": float(np.mean(rel <= TOL)),
+                                        "reference_itself_over_1e-5_of_fp64": int((~ref_ok).sum()),
+                                        "gpu_over_1e-5_of_fp64": int((np.abs(L - ref64) / ref64 > TOL).sum()),
+                                        "frac_within_where_reference_accurate": float(np.mean(rel[ref_ok] <= TOL)),
+                                        "p50": float(np.median(rel)), "p99": float(np.quantile(rel, 0.99)),
+                                        "max_rel": float(rel.max()), "bit_equal_frac": float(np.mean(L == Lref))})
+    assert np.mean(ref_ok) > 0.999
+    assert np.mean(rel[ref_ok] <= TOL) >= GATE
+
+
+def _draw_state(G, centres, u, dev):
+    """numpy's RandomState.choice restated on the d_min of `centres` (kmeans_optimized.py:47-61): returns the picked
+    index, the distance of u to the nearest cdf step (the draw's flip margin) and the normalised weights."""
+    from vqvae_amd.geo.geo_shortest_paths import sssp_multi_device
+    _, _, dmin, _, _ = sssp_multi_device(G, torch.from_numpy(np.asarray(centres, np.int32)).to(dev), want_D=False,
+                                         want_min=True)
+    d = dmin.cpu().numpy()
+    p = d ** 2
+    p[list(centres)] = 0.0
+    p /= p.sum()
+    cdf = p.astype(np.float64).cumsum()
+    cdf /= cdf[-1]
+    i = int(cdf.searchsorted(u, side="right"))
+    below = cdf[i - 1] if i > 0 else 0.0
+    return i, float(min(u - below, cdf[i] - u)), p, cdf, d
+
+
+def test_c2_draw_flip_margins_measured(c2, golden):
+    """WHY the end-to-end chains part ways (round-2 review, item 1b), from data: for every k-means++ draw up to the first
+    one that differs between the GPU's and the reference CLI's own edge lengths, the distance of the uniform deviate to
+    the nearest cdf step under both weight sets, and how far the two cdfs are apart at the drawn index.  A draw flips
+    when the cdf displacement (the accumulated effect of ALL edge-length differences on all d_min values before the
+    drawn node) exceeds that draw's margin.  Recorded in gpurun_out/parity_c2_flip_margins.json; DESIGN.md section 2
+    quotes it.  Asserted: the draws before the flip agree, and the flip is explained by displacement > margin."""
+    from scipy.sparse import csgraph
+    g = golden("c2_cli")
+    Gref, Lref = _graph_with_reference_lengths(c2, golden)
+    res, dev = c2["res"], c2["dev"]
+    Ggpu, Lgpu = res["W_lcc"], res["edge_lengths"].cpu().numpy()
+    med_ref, med_gpu = g["medoid_indices"].astype(np.int64), res["medoids"].astype(np.int64)
+    same = med_ref == med_gpu
+    if same.all():
+        _record("c2_flip_margins", {"chains_identical": True})
+        return
+    j = int(np.argmin(same))                                     # first centre that differs (centre j = draw j)
+    rng = np.random.RandomState(42)
+    assert int(rng.randint(0, N)) == med_ref[0] == med_gpu[0]
+    us = [float(rng.random_sample()) for _ in range(j)]          # one uniform per draw (legacy RandomState.choice)
+    margins_ref, margins_gpu, displacement = [], [], []
+    for t in range(1, j + 1):
+        centres = med_ref[:t].tolist()
+        i_ref, m_ref, p_ref, cdf_ref, d_ref = _draw_state(Gref, centres, us[t - 1], dev)
+        i_gpu, m_gpu, p_gpu, cdf_gpu, d_gpu = _draw_state(Ggpu, centres, us[t - 1], dev)
+        assert i_ref == med_ref[t]                               # the restated draw IS the reference's draw
+        assert i_gpu == med_gpu[t]
+        margins_ref.append(m_ref)
+        margins_gpu.append(m_gpu)
+        lo = max(i_ref - 1, 0)
+        displacement.append(float(max(abs(cdf_gpu[lo] - cdf_ref[lo]), abs(cdf_gpu[i_ref] - cdf_ref[i_ref]))))
+        if t < j:
+            assert i_ref == i_gpu
+    # the flipping draw: which nodes move the cdf, and which edges move those nodes
+    contrib = p_gpu - p_ref
+    upto = contrib[:med_ref[j]]
+    order = np.argsort(-np.abs(upto))[:8]
+    src, dst = (x.cpu().numpy() for x in res["edges"])
+    edge_rel = np.abs(Lgpu - Lref) / Lref
+    Wref = Gref.to_scipy()
+    nodes = []
+    for v in order.tolist():
+        dist, pred = csgraph.dijkstra(Wref, directed=False, indices=[int(v)], return_predecessors=True)
+        centre = min(med_ref[:j].tolist(), key=lambda c: dist[0, c])
+        path, node = [], centre
+        while node != v and node >= 0:                           # walk centre -> v along the tree rooted at v
+            nxt = int(pred[0, node])
+            a, b = (node, nxt) if node < nxt else (nxt, node)
+            e = int(np.flatnonzero((src == a) & (dst == b))[0])
+            path.append({"edge": e, "chunk": e // 512, "rel_diff_gpu_vs_ref": float(edge_rel[e])})
+            node = nxt
+        nodes.append({"node": int(v), "centre": int(centre), "d_min_ref": float(d_ref[v]),
+                      "d_min_rel_diff": float(abs(d_gpu[v] - d_ref[v]) / d_ref[v]), "cdf_contribution": float(contrib[v]),
+                      "path": path})
+    ulp_free = float(np.mean(Lgpu == Lref))
+    _record("c2_flip_margins", {
+        "chains_identical": False, "first_differing_centre": j, "draws_checked": j,
+        "margin_ref_min_before_flip": float(min(margins_ref[:-1])) if j > 1 else None,
+        "margin_ref_median": float(np.median(margins_ref)), "margin_ref_at_flip": margins_ref[-1],
+        "margin_gpu_at_flip": margins_gpu[-1], "cdf_displacement_at_flip": displacement[-1],
+        "cdf_displacement_median_before_flip": float(np.median(displacement[:-1])) if j > 1 else None,
+        "cdf_displacement_max_before_flip": float(max(displacement[:-1])) if j > 1 else None,
+        "sum_abs_contribution_before_drawn_node": float(np.abs(upto).sum()),
+        "edge_lengths_bit_equal_frac": ulp_free, "edge_rel_diff_p50": float(np.median(edge_rel)),
+        "edge_rel_diff_p99": float(np.quantile(edge_rel, 0.99)), "edge_rel_diff_max": float(edge_rel.max()),
+        "edges_over_1e-5": int((edge_rel > TOL).sum()),
+        "top_nodes_moving_the_cdf": nodes, "margins_ref": margins_ref, "displacements": displacement})
+    assert displacement[-1] >= margins_ref[-1] * 0.999           # the flip is a displacement beyond the draw's margin
+
+
 def test_c2_end_to_end_vs_reference_cli_measured(c2, golden):
     """North-star check at the headline size: codes / medoids of the GPU pipeline against the reference CLI's.
     The graph structure must be identical.  The 511 D^2 draws see edge weights that agree with the reference's only to
@@ -256,17 +417,33 @@ def test_c4_one_gpu_1m_latents_k1024():
     L = res["edge_lengths"].cpu().numpy()
     assert np.isfinite(L).all() and (L > 0).all()
     n_chunks = (len(src) + 511) // 512
-    # chunk 0 (512 edges out of ~17 distinct start points: |mean| >> std in its BatchNorm batch, float32
-    # pre-activation rounding is amplified ~1e4-fold there, for the reference as for us) is recorded, not gated
-    for c in (0, 1000, n_chunks // 2, n_chunks - 1):
-        sl = slice(c * 512, min((c + 1) * 512, len(src)))
-        ref = om.edge_lengths(ctx["sd"], "batch", 28, ctx["z_h"][src[sl]], ctx["z_h"][dst[sl]], batch_size=512,
-                              training=True, dtype=torch.float64).numpy()
-        rel = np.abs(L[sl] - ref) / ref
-        if c == 0:
-            _record("c4_jvp_chunk0_vs_fp64", {"frac_within": float(np.mean(rel <= TOL)), "max_rel": float(rel.max())})
-            continue
-        assert np.mean(rel <= TOL) >= 0.995 and np.quantile(rel, 0.99) < 2e-6, (c, rel.max())
+    # 256 chunks spread over the run (+ chunk 0, the one round 2 exempted by index) against the fp64 closed form.  Which of
+    # them may miss the gate is decided by the CRITERION near0 < NEAR0 (a ReLU-boundary sample in the chunk), not by index:
+    # those are recorded (and still held to a median error below 1e-6), every other sampled chunk is gated.
+    sample = np.unique(np.concatenate([[0], np.linspace(0, n_chunks - 2, 256).astype(np.int64)]))
+    pick = np.concatenate([np.arange(c * 512, (c + 1) * 512) for c in sample])
+    ref, cond = om.edge_lengths_dense(ctx["sd"], 28, ctx["z_h"][src[pick]], ctx["z_h"][dst[pick]], batch_size=512,
+                                      dtype=torch.float64, device="cuda", with_conditioning=True)
+    c_chk = int(sample[len(sample) // 2])                           # the checker itself on one chunk: dense GPU == conv CPU
+    cpu64 = om.edge_lengths(ctx["sd"], "batch", 28, ctx["z_h"][src[c_chk * 512:(c_chk + 1) * 512]],
+                            ctx["z_h"][dst[c_chk * 512:(c_chk + 1) * 512]], batch_size=512, training=True, dtype=torch.float64).numpy()
+    np.testing.assert_allclose(ref.numpy()[(len(sample) // 2) * 512:(len(sample) // 2 + 1) * 512], cpu64, rtol=2e-6)
+    rel = (np.abs(L[pick] - ref.numpy()) / ref.numpy()).reshape(len(sample), 512)
+    R, near0 = cond.numpy()[:, 0], cond.numpy()[:, 1]
+    flagged = near0 < NEAR0
+    frac_over = (rel > TOL).mean(axis=1)
+    _record("c4_jvp_sampled_chunks_vs_fp64", {
+        "sampled_chunks": int(len(sample)), "near0_threshold": NEAR0, "flagged_chunks": int(flagged.sum()),
+        "flagged_with_an_edge_over": [{"chunk": int(c), "near0": float(m), "frac_over": float(f)}
+                                      for c, m, f in zip(sample[flagged], near0[flagged], frac_over[flagged]) if f > 0],
+        "flagged_frac_within": float((rel[flagged] <= TOL).mean()), "flagged_median": float(np.median(rel[flagged])),
+        "gated_chunks": int((~flagged).sum()), "gated_frac_within": float((rel[~flagged] <= TOL).mean()),
+        "gated_worst_chunk_frac_over": float(frac_over[~flagged].max()), "gated_p99": float(np.quantile(rel[~flagged], 0.99)),
+        "gated_max_rel": float(rel[~flagged].max()), "R_max_mean_over_std": float(R.max())})
+    assert (~flagged).sum() >= 64
+    assert (rel[~flagged] <= TOL).mean() >= GATE and np.quantile(rel[~flagged], 0.99) < 2e-6
+    assert frac_over[~flagged].max() <= 1 / 512 + 1e-9               # at most one stray edge in any unflagged chunk
+    assert np.median(rel[flagged]) < 1e-6
     med, assign = res["medoids"], res["assign_flat"]
     assert len(set(med.tolist())) == K and (assign >= 0).all() and (assign < K).all()
     assert (assign[med] == np.arange(K)).all()
