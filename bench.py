@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- latents/s through the geodesic-codebook hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss|real|c5cb]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU
@@ -51,10 +51,25 @@ WORKLOADS = {
     # second latent distribution -- noisy 2-D swiss roll embedded in d dims (long geodesics,
     # many relaxation sweeps); same decoder / k / K as c2
     "swiss": (60000, 16, 1, 28, 20, 512),
+    # the shapes the reference's pipeline really feeds build_codebook.py (SURVEY finding 7: N*H*W nodes, build_codebook.py:35):
+    "real": (960000, 16, 1, 28, 20, 512),       # FashionMNIST: 60 000 images x 4x4 cells, d=16, K=512
+    "c5cb": (800000, 32, 3, 32, 20, 512),       # CIFAR-10 (BASELINE config 5's codebook stage): 50 000 x 4x4 cells, d=32, 32-px decoder
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak = half the 157.3 TFLOP/s f32 vector peak of MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 (the JVP's ConvT2 / ConvT3 products run as 6 bf16 MFMAs per f32 product)
+
+
+def jvp_flop_per_edge(d, cout, size, channels=(256, 128, 64)):
+    """f32 flop of one edge of the pull-back metric from the decoder's shape: 2 endpoints x (primal + tangent) x 2 flop per
+    MAC of conv1x1(d->c0), ConvT(c0->c1) 1x1->2x2 (4 taps), ConvT(c1->c2) 2x2->4x4 (36 valid input/output pixel pairs),
+    ConvT(c2->cout) 4x4->4x4 (28-px head, padding 3: 64 pairs) or 4x4->8x8 (32-px head, padding 1: 196 pairs).
+    d=16, 28-px, 1 channel: 434 176 MAC -> 3.47 MFLOP."""
+    c0, c1, c2 = channels
+    pairs3 = 64 if int(size) == 28 else 196
+    mac = d * c0 + 4 * c0 * c1 + 36 * c1 * c2 + pairs3 * c2 * cout
+    return 8.0 * mac
 
 
 def cpu_model():
@@ -116,7 +131,8 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
         ms_, launches_ = np.zeros(1, np.float64), np.zeros(1, np.int32)
         layout = _lib.load().geo_sssp_last_profile(ms_.ctypes.data, launches_.ctypes.data)
         prof["ms"], prof["launches"], prof["sources"] = float(ms_[0]), int(launches_[0]), s1 - s0
-        prof["kernel"] = ("sweep_chunk32u_kernel" if layout >= 2000 else "sweep_chunk16_kernel" if layout >= 1000
+        prof["kernel"] = ("push_sweep_kernel" if layout >= 4000 else "sweep_chunk32u_kernel" if layout >= 2000
+                          else "sweep_chunk16_kernel" if layout >= 1000
                           else f"sweep_multi_kernel<{layout}>")
         return dmin_, arg_
 
@@ -168,7 +184,7 @@ def cpu_baseline(res, z, dec, cfg, full):
                   f"{cores} threads), k-medoids {n_solves} heap-Dijkstra solves (1 thread, as scipy in the reference); "
                   f"port medoids/QE equal the GPU's: {agree}")
     else:
-        n_src = 24
+        n_src = 24 if n <= 200000 else 6            # (one heap-Dijkstra solve over 1 M nodes takes ~2.5 s)
         t0 = time.perf_counter()
         osp.dijkstra_multi_source(W, res["medoids"][:n_src])
         t_kmed = (time.perf_counter() - t0) / min(n_src, len(res["medoids"])) * n_solves
@@ -281,6 +297,11 @@ def main():
         if tj.get("kernel") == res["sweep_kernel"]:
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = f"profiles/traffic_latest.json (separate rocprofv3 --pmc passes, run {tj.get('tag', '?')}); not measured in this run"
+    # what the DISPATCHED kernel must move per (edge, source) and per (node, source) -- beside SURVEY 8(d)'s 16 + 16 model:
+    #   32-bit fixed point: 4 B distance gather + 8 B of CSR entry (column, weight units) shared by 32 sources; 4 B read + 4 B write
+    #   fp64 kernels:       8 B distance gather + 8 B of CSR entry shared by 16 sources;                       8 B read + 8 B write
+    per_edge, per_node = (4.0 + 8.0 / 32, 8.0) if res["sweep_kernel"] == "sweep_chunk32u_kernel" else (8.0 + 8.0 / 16, 16.0)
+    kernel_bytes = res["sources_this_rank"] * (per_edge * nnz + per_node * n)
     ms_per_step = elapsed / args.steps * 1e3
     stages_ms = {k_: v * 1e3 / args.steps for k_, v in timers.items()}
     sharded = res.get("sharded", {})
@@ -295,7 +316,7 @@ def main():
         "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] / (elapsed / args.steps),
         "unit": "latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64-exact(u32 fixed point)" if res["sweep_kernel"] == "sweep_chunk32u_kernel" else "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={cfg['n']} latents d={cfg['d']} k={cfg['k']} K={cfg['K']} "
                                f"{cfg['size']}px decoder BN-train batch 512 sym=union init=kpp seed=42",
                    "graph": {"nodes": n, "nnz": nnz, "edges_reweighted": res["n_edges"]},
@@ -304,7 +325,12 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": res["sweep_kernel"], "launches_per_step": launches,
                      "avg_launch_ms": sweep_ms / max(1, launches),
-                     "algorithmic_bytes_per_launch": algo_bytes / max(1, launches)},
+                     "algorithmic_bytes_per_launch": algo_bytes / max(1, launches),
+                     # the kernel's own minimum traffic (ONE relaxation of every entry, see above) and what the run moved
+                     # relative to it: label correcting evaluates a row several times, so `passes_over_minimum` > 1
+                     "kernel_bytes": kernel_bytes, "frac_kernel_bytes": (kernel_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms > 0 else 0.0,
+                     "frac_counters": (traffic * launches / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and sweep_ms > 0) else None,
+                     "passes_over_minimum": (traffic * launches / kernel_bytes) if (traffic and kernel_bytes) else None},
         "stages_ms": stages_ms,
         "parity_selfcheck": {"batched_assign_equals_fused": same, "qe": res["qe"]},
     }
@@ -317,10 +343,28 @@ def main():
                                "unit": "TFLOP/s", "frac": fl / (stages_ms["knn"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                "model": "2*N^2*d flop / kNN stage time (search + symmetrise + edge list)"}
     if stages_ms.get("jvp"):
-        fl = 3.47e6 * res["n_edges"] * share
-        out["roofline_jvp"] = {"bound": "mfma-f32", "achieved": fl / (stages_ms["jvp"] * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": fl / (stages_ms["jvp"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                               "model": "3.47 MFLOP/edge (SURVEY 8d, 28-px decoder) / JVP stage time"}
+        per_edge_fl = jvp_flop_per_edge(cfg["d"], cfg["cout"], cfg["size"])
+        fl = per_edge_fl * res["n_edges"] * share
+        eff = fl / (stages_ms["jvp"] * 1e-3) / 1e12
+        out["roofline_jvp"] = {"bound": "mfma-f32 (EFFECTIVE f32 flop: the products run as 6 bf16 MFMAs each)", "achieved": eff,
+                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": eff / F32_MFMA_PEAK_TFLOPS,
+                               "flop_per_edge": per_edge_fl,
+                               # matrix-pipe view of the same stage: issued bf16 flop (6 x the f32 MACs of ConvT2 + ConvT3, the
+                               # layers that run on MFMA) against the dense bf16 peak; MFMA-busy cycles are in profiles/
+                               "frac_bf16_peak": 6.0 * eff / BF16_MFMA_PEAK_TFLOPS,
+                               "model": f"{per_edge_fl / 1e6:.2f} MFLOP/edge from the decoder shape (d={cfg['d']}, {cfg['size']}-px, "
+                                        f"{cfg['cout']} ch) / JVP stage time (whole stage: first layer, BatchNorm statistics, ConvT2, head)"}
+    # multi-GPU accounting: bytes each rank RECEIVES per step in the all-gather merges, and the part of the step
+    # that does not shard (the k-means++ chain + component labelling are replicated) -- the first scaling line explains itself
+    E = res["n_edges"]
+    out["comm_bytes_per_step"] = {
+        "latents_all_gather": int(cfg["n"] * cfg["d"] * 4 * (world - 1) / world) if world > 1 else 0,
+        "knn_lists_all_gather": int(cfg["n"] * (cfg["k"] + 1) * 4 * (world - 1) / world) if world > 1 else 0,
+        "edge_lengths_all_gather": int(E * 4 * (world - 1) / world) if world > 1 else 0,
+        "assign_min_argmin_all_gather": int(n * 8 * (world - 1)) if world > 1 else 0}
+    serial_ms = stages_ms.get("kmedoids", 0.0) + stages_ms.get("lcc", 0.0)
+    out["serial_fraction"] = {"ms_not_sharded": serial_ms, "of_step": serial_ms / ms_per_step if ms_per_step > 0 else None,
+                              "amdahl_limit_8_gpus": (ms_per_step / (serial_ms + (ms_per_step - serial_ms) / 8.0)) if world == 1 and ms_per_step > 0 else None}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             full = args.workload in ("c1", "c2") and os.environ.get("GEO_BENCH_CPU_SAMPLE", "0") != "1"

@@ -70,8 +70,15 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
 /* Device time (ms, HIP events on the call's stream) spent in the relaxation sweeps of the last
  * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
  * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel,
- * 2032 for the exact 32-bit fixed-point kernel (32 sources per row). */
+ * 2032 for the exact 32-bit fixed-point kernel (32 sources per row), 4016 for the near-far push solve
+ * (long geodesics: sources ordered along landmark distances, 16 per batch, delta-stepping buckets). */
 int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
+
+/* The layout geo_sssp_multi would START with for a graph of n nodes and n_sources sources (host arithmetic only, no GPU
+ * call): sources per batch (16 or 64), +1000 when the 16-edge-chunk kernels run, +2000 more when the exact 32-bit
+ * fixed-point solve is tried first.  The 16- / 32-source row layouts address a batch with 32-bit byte offsets and are
+ * therefore never chosen for n >= 2^25 nodes.  Negative on bad arguments. */
+int geo_sssp_plan(int32_t n, int32_t n_sources);
 
 /* One source; fused k-means++ bookkeeping of kmeans_optimized.py:43-44 and the single-pass
  * assignment: d32 = f32(dist(source, .)); where d32 < dmin: dmin = d32, argmin = center_pos.

@@ -107,6 +107,41 @@ def build_knn_graph(z, k=10, metric="euclidean", mode="distance", sym="mutual"):
     return build_knn_graph_auto(z, k=k, metric=metric, mode=mode, sym=sym)
 
 
+def build_knn_graph_faiss_semantics(z, k=10, metric="euclidean", mode="distance", sym="mutual"):
+    """knn_graph_optimized.py:70-126 with faiss.IndexFlatL2 / IndexFlatIP restated from their published definition
+    (faiss 1.x, not installed here: PARITY UNPINNED): exhaustive search, `search` returns SQUARED L2 distances resp. inner
+    products as float32, nearest / largest first.  Small inputs only (dense N x N matrix)."""
+    z = np.asarray(z)
+    N = z.shape[0]
+    if metric == "euclidean":
+        x = np.ascontiguousarray(z.astype(np.float32)).astype(np.float64)
+        score = ((x[:, None, :] - x[None, :, :]) ** 2).sum(axis=2)
+        order = np.argsort(score, axis=1, kind="stable")[:, :min(k + 1, N)]
+        dist = np.take_along_axis(score, order, axis=1).astype(np.float32)
+    elif metric == "cosine":
+        x = np.ascontiguousarray((z / (np.linalg.norm(z, axis=1, keepdims=True) + 1e-8)).astype(np.float32)).astype(np.float64)
+        sim = x @ x.T
+        order = np.argsort(-sim, axis=1, kind="stable")[:, :min(k + 1, N)]
+        dist = (np.float32(1.0) - np.take_along_axis(sim, order, axis=1).astype(np.float32)).astype(np.float32)
+    else:
+        raise ValueError(f"FAISS metric '{metric}' not supported. Use 'euclidean' or 'cosine'.")
+    idx = order.astype(np.int64)
+    if idx.shape[1] > 1 and (idx[:, 0] == np.arange(N)).all():
+        dist, idx = dist[:, 1:], idx[:, 1:]
+    kk = idx.shape[1]
+    data = dist.ravel() if mode == "distance" else np.ones(N * kk, dtype=np.float32)
+    W = sparse.csr_matrix((data, (np.repeat(np.arange(N), kk), idx.ravel())), shape=(N, N))
+    if sym == "mutual":
+        W = W.minimum(W.T)
+    elif sym == "union":
+        W = W.maximum(W.T)
+    else:
+        raise ValueError(f"Invalid symmetry mode: {sym}")
+    W.setdiag(0.0)
+    W.eliminate_zeros()
+    return W.tocsr(), {"distances": dist, "indices": idx}
+
+
 def connected_components(W: sparse.spmatrix) -> Tuple[int, np.ndarray]:
     W = sparse.csr_matrix(W)
     WT = W.T.tocsr()

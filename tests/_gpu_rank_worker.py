@@ -29,7 +29,7 @@ def main(out_dir):
     else:
         dist.init_process_group(backend)
     try:
-        n, d, K = 2048, 16, 64
+        n, d, K = (int(v) for v in os.environ.get("GEO_TEST_SHAPE", "2048,16,64").split(","))
         z_h = syn.gauss_latents(n, d, 0)
         sd = om.make_decoder_state(0, d, 1, norm_type="batch")
         dec = SpatialDecoder(1, (256, 128, 64), d, 28, "batch")
@@ -52,7 +52,8 @@ def main(out_dir):
                  indices=G.indices.cpu().numpy(), data=G.data.cpu().numpy(), lengths=res["edge_lengths"].cpu().numpy(),
                  medoids=res["medoids"], assign=res["assign_flat"], qe=np.float64(res["qe"]),
                  dmin=dmin.cpu().numpy(), arg=arg.cpu().numpy(),
-                 sharded=np.array([int(res["sharded"]["knn"]), int(res["sharded"]["jvp"])]))
+                 sharded=np.array([int(res["sharded"]["knn"]), int(res["sharded"]["jvp"])]),
+                 **{"bn/" + k: v.cpu().numpy() for k, v in dec.state_dict().items() if "running" in k or "tracked" in k})
     finally:
         dist.destroy_process_group()
 

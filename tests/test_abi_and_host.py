@@ -189,3 +189,17 @@ def test_cli_flag_set_is_the_reference_one():
     assert args.mse_use_sigmoid is False and args.dec_channels == [256, 128, 64]
     with pytest.raises(SystemExit):
         make_parser().parse_args(["--latents_path", "z.pt"])
+
+
+def test_sssp_plan_keeps_32bit_row_offsets_below_2_pow_25_nodes():
+    """The 16- / 32-source row kernels gather through 32-bit byte offsets (node << 7): geo_sssp_plan (the choice
+    geo_sssp_multi makes, host arithmetic only) must never pick them once n * 128 bytes reaches 2^32."""
+    from vqvae_amd import _lib
+    plan = _lib.load().geo_sssp_plan
+    assert plan(60000, 512) == 16 + 1000 + 2000                  # C2: chunked rows, fixed point tried first
+    assert plan(1_000_000, 1024) == 16 + 1000 + 2000             # C4
+    assert plan((1 << 25) - 1, 512) == 16 + 1000 + 2000
+    assert plan(1 << 25, 512) == 64                              # 64-bit indexing only from here on
+    assert plan(40_000_000, 1024) == 64
+    assert plan(1 << 25, 8) == 16                                # few sources: the 16-source NODE kernel (size_t indices)
+    assert plan(2048, 64) == 64 and plan(0, 4) < 0

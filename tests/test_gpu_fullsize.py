@@ -133,7 +133,7 @@ def _all_chunks_vs_fp64(ctx, name):
                                     "frac_within_flagged_chunks": float(np.mean(rel[~clear_edges] <= TOL)),
                                     "R_max_mean_over_std": float(R.max()), "R_median": float(np.median(R))})
     assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
-    assert np.mean(rel[clear_edges] <= TOL) >= 0.9999               # chunks without a boundary sample: (almost) every edge
+    assert rel[clear_edges].max() <= TOL                            # chunks without a boundary sample: EVERY edge
     assert (~flagged).sum() >= 64
     assert np.quantile(rel, 0.99) < 2e-6
     ctx["_vs_fp64"] = (rel, ref64)
@@ -270,7 +270,7 @@ def test_c2_all_reference_edge_lengths_vs_gpu(c2, golden):
                                         "frac_within_where_reference_accurate": float(np.mean(rel[ref_ok] <= TOL)),
                                         "p50": float(np.median(rel)), "p99": float(np.quantile(rel, 0.99)),
                                         "max_rel": float(rel.max()), "bit_equal_frac": float(np.mean(L == Lref))})
-    assert np.mean(ref_ok) > 0.999
+    assert np.mean(ref_ok) > 0.998                                  # (the reference's own float32 misses fp64 on 0.14 %)
     assert np.mean(rel[ref_ok] <= TOL) >= GATE
 
 
@@ -442,7 +442,7 @@ def test_c4_one_gpu_1m_latents_k1024():
         "gated_max_rel": float(rel[~flagged].max()), "R_max_mean_over_std": float(R.max())})
     assert (~flagged).sum() >= 64
     assert (rel[~flagged] <= TOL).mean() >= GATE and np.quantile(rel[~flagged], 0.99) < 2e-6
-    assert frac_over[~flagged].max() <= 1 / 512 + 1e-9               # at most one stray edge in any unflagged chunk
+    assert rel[~flagged].max() <= TOL                                # chunks without a boundary sample: EVERY edge
     assert np.median(rel[flagged]) < 1e-6
     med, assign = res["medoids"], res["assign_flat"]
     assert len(set(med.tolist())) == K and (assign >= 0).all() and (assign < K).all()

@@ -303,3 +303,56 @@ def test_cosine_and_other_metrics_vs_reference(golden):
             assert info["distances"].dtype == np.float32
     with pytest.raises(ValueError):
         build_knn_graph_auto(latents(64, 8, 0), k=5, metric="no-such-metric")
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_faiss_semantics_opt_in_equals_the_restated_indexflat(metric):
+    """a reference WITH faiss takes build_knn_graph_faiss at every headline size (N >= 50 000).  Its
+    semantics -- squared float32 L2 distances / 1 - <x^, y^>, self column dropped only when it leads every row -- on the HIP
+    search, opt-in (vqvae_amd.geo.knn_graph_optimized.FAISS_SEMANTICS), against the numpy restatement of IndexFlatL2 /
+    IndexFlatIP in oracle/knn.py.  PARITY UNPINNED (faiss is not installed where the fixtures are made)."""
+    from oracle import knn as okn
+    from vqvae_amd.geo import knn_graph_optimized as kg
+    z = latents(700, 16, 41)
+    kg.FAISS_SEMANTICS = True
+    try:
+        for mode, sym in (("distance", "union"), ("connectivity", "mutual")):
+            W, info = kg.build_knn_graph_auto(z, k=12, metric=metric, mode=mode, sym=sym, force_method="faiss")
+            Wo, io = okn.build_knn_graph_faiss_semantics(z, k=12, metric=metric, mode=mode, sym=sym)
+            W.sort_indices(); Wo.sort_indices()
+            np.testing.assert_array_equal(info["indices"], io["indices"])
+            assert info["distances"].dtype == np.float32 and info["indices"].dtype == np.int64
+            np.testing.assert_allclose(info["distances"], io["distances"], rtol=2e-6, atol=2e-7)
+            np.testing.assert_array_equal(W.indptr, Wo.indptr)
+            np.testing.assert_array_equal(W.indices, Wo.indices)
+            np.testing.assert_allclose(W.data, Wo.data, rtol=2e-6, atol=2e-7)
+        # the automatic choice follows the reference's size threshold once the semantics are switched on
+        Wa, ia = kg.build_knn_graph_auto(z, k=5, metric=metric, mode="distance", sym="union", size_threshold=500)
+        Wf, _ = kg.build_knn_graph_faiss(z, k=5, metric=metric, mode="distance", sym="union")
+        assert (Wa != Wf).nnz == 0
+        Ws, _ = kg.build_knn_graph_auto(z, k=5, metric=metric, mode="distance", sym="union", size_threshold=5000)
+        assert abs(Ws.data.max() - np.sqrt(Wa.data.max())) < 1e-5 if metric == "euclidean" else True
+        with pytest.raises(ValueError):
+            kg.build_knn_graph_faiss(z, k=5, metric="manhattan")
+    finally:
+        kg.FAISS_SEMANTICS = False
+    with pytest.raises(RuntimeError):
+        kg.build_knn_graph_faiss(z, k=5)
+
+
+def test_cosine_graph_with_a_zero_latent_follows_sklearn(golden):
+    """A latent that is exactly zero is at cosine distance 1.0 from every row in the reference (sklearn leaves a zero
+    row un-normalised), not at 0.5 (what |x^ - y^|^2 / 2 on unit rows would say).  Fixture: the reference's own lists for
+    every row but the zero one (tests/golden/knn_cosine_zero.npz)."""
+    from oracle import synthetic as syn
+    from vqvae_amd.geo.knn_graph_optimized import build_knn_graph_auto
+    g = golden("knn_cosine_zero")
+    z = syn.gauss_latents(400, 16, 31)
+    z[17] = 0.0
+    W, info = build_knn_graph_auto(z, k=10, metric="cosine", mode="distance", sym="union")
+    rows = g["rows"]
+    np.testing.assert_array_equal(info["indices"][rows], g["nbr_indices"])
+    np.testing.assert_allclose(info["distances"][rows], g["nbr_distances"], rtol=0, atol=2e-7)
+    assert not (info["indices"][rows] == 17).any()                       # nobody is near the zero latent
+    np.testing.assert_allclose(info["distances"][17], g["zero_row_distances"], atol=1e-7)      # all 1.0
+    assert W[17].nnz == 10 and np.allclose(W[17].data, 1.0)

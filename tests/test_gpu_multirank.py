@@ -20,29 +20,39 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _single_process():
+def _single_process(n=2048, K=64):
     from oracle import metric as om
     from oracle import synthetic as syn
     from vqvae_amd._device import device
     from vqvae_amd.scripts.build_codebook import build_codebook_device
     from vqvae_amd.spatial_decoder import SpatialDecoder
     dev = device()
-    z_h = syn.gauss_latents(2048, 16, 0)
+    z_h = syn.gauss_latents(n, 16, 0)
     sd = om.make_decoder_state(0, 16, 1, norm_type="batch")
     dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "batch")
     dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    res = build_codebook_device(torch.from_numpy(z_h).to(dev), dec.to(dev).train(), k=20, sym="union", K=64,
+    dec = dec.to(dev).train()
+    res = build_codebook_device(torch.from_numpy(z_h).to(dev), dec, k=20, sym="union", K=K,
                                 init="kpp", seed=42, batch_size=512)
+    res["bn"] = {k: v.cpu().numpy() for k, v in dec.state_dict().items() if "running" in k or "tracked" in k}
     return z_h, res
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_on_hip_kernels_equal_single_process(tmp_path, world):
+def _backend(world):
+    """RCCL ("nccl") when the box has a GPU per rank -- the driver's multi-GPU node --, else gloo with the ranks sharing
+    the GPU(s) that are there (RCCL refuses two ranks on one device)."""
+    return "nccl" if torch.cuda.device_count() >= world else "gloo"
+
+
+@pytest.mark.parametrize("world,shape", [(2, (2048, 16, 64)), (3, (2048, 16, 64)), (2, (60000, 16, 512))],
+                         ids=["w2-c1", "w3-c1", "w2-c2"])
+def test_ranks_on_hip_kernels_equal_single_process(tmp_path, world, shape):
     port = _free_port()
     procs = []
     for rank in range(world):           # fresh interpreters: nothing that touched the GPU is forked or re-executed
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   GEO_TEST_BACKEND=_backend(world), GEO_TEST_SHAPE=",".join(str(v) for v in shape))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(tmp_path)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -55,7 +65,7 @@ def test_ranks_on_hip_kernels_equal_single_process(tmp_path, world):
             raise
         logs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
-    z_h, res = _single_process()
+    z_h, res = _single_process(shape[0], shape[2])
     G = res["W_lcc"]
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
@@ -69,3 +79,10 @@ def test_ranks_on_hip_kernels_equal_single_process(tmp_path, world):
         np.testing.assert_array_equal(got["assign"], res["assign_flat"])
         assert float(got["qe"]) == res["qe"]
         np.testing.assert_array_equal(got["arg"], res["assign_flat"])            # sharded assignment == fused chain
+        # BatchNorm buffers: identical on every rank, and the single-process values up to float32 re-association
+        for key, want in res["bn"].items():
+            np.testing.assert_array_equal(got["bn/" + key], np.load(os.path.join(str(tmp_path), "rank0.npz"))["bn/" + key])
+            if "tracked" in key:
+                assert int(got["bn/" + key]) == int(want)
+            else:
+                np.testing.assert_allclose(got["bn/" + key], want, rtol=2e-5, atol=1e-7)

@@ -426,3 +426,105 @@ def test_large_graph_takes_fixed_point_layout_and_falls_back_to_64_source_batche
     np.testing.assert_array_equal(dijkstra_multi_source(Wide, src), osp.dijkstra_multi_source(Wide, src))
     assert _lib.load().geo_sssp_last_profile(None, None) == 64            # declined -> 64 sources per batch
 
+
+
+def _set_options(request, **opts):
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    defaults = {"sssp_sb": -1, "sssp_push": 1, "sssp_delta": 4, "sssp_u32": 1, "sssp_group": 1, "sssp_push_blocks": 64}
+    for name, value in opts.items():
+        _lib.check(lib.geo_set_option(name.encode(), int(value)), "geo_set_option")
+        request.addfinalizer(lambda name=name: lib.geo_set_option(name.encode(), defaults[name]))
+
+
+def _jvp_like_weights(W, seed):
+    """Symmetric weights spread over a factor ~16 (0.0136 .. 0.21, as the decoder pull-back lengths of the swiss bench
+    graph): min-hop and min-weight paths differ a lot, which is what makes plain label correcting expensive.  seed 0
+    skews them towards the top of the range, so that ~120-hop geodesics reach 3-4 x 2^32 units of the smallest weight's
+    last bit: eligible for the 32-bit fixed-point solve by their range (5 binades), too long for it."""
+    from oracle.synthetic import formula_weights
+    rows = np.repeat(np.arange(W.shape[0]), np.diff(W.indptr))
+    f = formula_weights(np.minimum(rows, W.indices), np.maximum(rows, W.indices)).astype(np.float64)     # in [0.5, 1.5)
+    W = W.copy()
+    W.data = (0.0136 * np.exp2(np.clip(f - 0.5, 0.0, 1.0) ** (0.25 if seed == 0 else 1.0) * 4.0)).astype(np.float32)
+    return W
+
+
+def test_long_geodesics_with_wide_weights_take_the_near_far_push_solve(request):
+    """The bench's `swiss` regime in small: ~100-hop geodesics whose weights need more than 32 bits of fixed-point
+    units.  The dispatch must order the sources and hand them to the near-far push solve (layout 4016); distances,
+    predecessors, column minimum and first-row argmin equal the oracle's."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from vqvae_amd import _lib
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    n = 40000                                  # (k = 6: ~250-hop geodesics, landmark eccentricity beyond 2^32 weight units)
+    W, _ = okn.build_knn_graph(swiss_roll_latents(n, 16, 3), k=6, mode="connectivity", sym="union")
+    W = _jvp_like_weights(W.tocsr(), 0)
+    src = np.random.RandomState(5).choice(n, 100, replace=False)
+    src = np.concatenate([src, src[[3, 40, 69]]])
+    Do, Po = osp.dijkstra_multi_source(W, src, return_predecessors=True)
+    D, P = dijkstra_multi_source(W, src, return_predecessors=True)
+    assert _lib.load().geo_sssp_last_profile(None, None) == 4016
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal((P < 0), (Po < 0))
+    rows, cols = np.nonzero(np.isfinite(Do) & (P >= 0))
+    w_pv = np.asarray(W[P[rows, cols], cols]).ravel().astype(np.float64)
+    assert np.all(np.abs(Do[rows, P[rows, cols]].astype(np.float64) + w_pv - Do[rows, cols]) <= 1e-5 * (1 + Do[rows, cols]))
+    G = DeviceCSR.from_scipy(W, device())
+    _, _, dmin, arg, sweeps = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
+    np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+    np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+
+
+@pytest.mark.parametrize("delta", [1, 4, 1000000])
+def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, request):
+    """`sssp_push=2` + 16-source batches send EVERY call with more than 16 sources through the push solve, whatever the
+    graph: Gaussian clouds and swiss rolls, one binade of weights or eleven, unweighted, a disconnected graph (inf
+    columns, idle batches), duplicate and padded sources, for a narrow bucket (delta = 1 mean weight: many release
+    sweeps), the default and an infinite one (plain push label correcting).  All equal the oracle bit for bit."""
+    import torch
+    from oracle import knn as okn
+    from oracle import sssp as osp
+    from oracle.synthetic import formula_weights
+    from vqvae_amd import _lib
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta)
+    rs = np.random.RandomState(77)
+    cases = [(3000, 6, 17, False, 0), (9000, 4, 33, True, 1), (15000, 10, 70, False, 2), (12000, 6, 130, True, 2),
+             (6000, 4, 40, True, 0), (3000, 4, 130, True, 3)]
+    for case, (n, k, S, roll, mode) in enumerate(cases):
+        z = swiss_roll_latents(n, 8, case) if roll else latents(n, 8, case)
+        W, _ = okn.build_knn_graph(z, k=k, mode="distance", sym="union")
+        W = W.tocsr()
+        if mode == 3:
+            W = _jvp_like_weights(W, case)
+        elif mode:
+            rows = np.repeat(np.arange(n), np.diff(W.indptr))
+            f = formula_weights(rows, W.indices).astype(np.float64)
+            W.data = (f if mode == 1 else f * np.exp2(np.floor((f - 0.5) * 11.0))).astype(np.float32)
+        src = rs.choice(n, S, replace=False)
+        src[-1] = src[0]                                                # a duplicate source
+        Do = osp.dijkstra_multi_source(W, src)
+        np.testing.assert_array_equal(dijkstra_multi_source(W, src), Do, err_msg=str((case, n, k, S, roll, mode)))
+        assert _lib.load().geo_sssp_last_profile(None, None) == 4016
+        G = DeviceCSR.from_scipy(W, device())
+        _, _, dmin, arg, _ = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
+        np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
+        np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+    # unweighted + predecessors, and two components (sources in both; unreachable = inf, predecessor -9999)
+    W, _ = okn.build_knn_graph(latents(5000, 8, 9), k=6, mode="distance", sym="union")
+    src = rs.choice(5000, 40, replace=False)
+    np.testing.assert_array_equal(dijkstra_multi_source(W, src, unweighted=True), osp.dijkstra_multi_source(W, src, unweighted=True))
+    A, _ = okn.build_knn_graph(latents(3000, 8, 1), k=6, mode="distance", sym="union")
+    B, _ = okn.build_knn_graph(swiss_roll_latents(2500, 8, 2), k=6, mode="distance", sym="union")
+    Wd = sparse.block_diag((A, B), format="csr", dtype=np.float32)
+    src = np.concatenate([rs.choice(3000, 20, replace=False), 3000 + rs.choice(2500, 20, replace=False)])
+    Do, Po = osp.dijkstra_multi_source(Wd, src, return_predecessors=True)
+    D, P = dijkstra_multi_source(Wd, src, return_predecessors=True)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(P < 0, Po < 0)
+    assert np.isinf(D[:20, 3000:]).all() and np.isinf(D[20:, :3000]).all()

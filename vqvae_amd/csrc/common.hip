@@ -17,6 +17,9 @@ const OptionName kOptionNames[] = {
     {"sssp_grouped_cap", "GEO_SSSP_GROUPED_CAP", &Options::sssp_grouped_cap},
     {"sssp_trace", "GEO_SSSP_TRACE", &Options::sssp_trace},
     {"sssp_u32", "GEO_SSSP_U32", &Options::sssp_u32},
+    {"sssp_push", "GEO_SSSP_PUSH", &Options::sssp_push},
+    {"sssp_delta", "GEO_SSSP_DELTA", &Options::sssp_delta},
+    {"sssp_push_blocks", "GEO_SSSP_PUSH_BLOCKS", &Options::sssp_push_blocks},
     {"knn_filter", "GEO_KNN_FILTER", &Options::knn_filter},
     {"kpp_grid", "GEO_KPP_GRID", &Options::kpp_grid},
     {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},

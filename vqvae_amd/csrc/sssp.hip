@@ -502,6 +502,229 @@ __global__ __launch_bounds__(256) void sweep_chunk32u_kernel(const int32_t *__re
     }
 }
 
+// ---- near-far push solve: long geodesics -------------------------------------------------------------------------
+// Label-correcting PULL sweeps re-read a whole row whenever any of its ~25 neighbours moved for any source of the batch;
+// on a graph with ~150-hop geodesics and edge weights spread over a factor 16 (pull-back lengths on a manifold-like
+// latent cloud) that is ~27 row evaluations per row and ~7 improvements per (node, source) -- measured, DESIGN.md.
+// This solve is the GPU form of delta-stepping (north_star names it; scipy's Dijkstra settles each node once,
+// geo_shortest_paths.py:36-49): work is driven from the rows that CHANGED (push), and a changed row relaxes its edges
+// only once its distance is below the batch's threshold theta (near); rows beyond wait in a far pile until the near
+// work has drained and theta advances by delta.  Measured in simulation on the swiss-roll bench graph: 4 pushed rows
+// per row instead of 27 evaluated rows, 1.9 improvements per pair instead of 6.9.
+//
+// Exactness: every stored value is the fp64 left-to-right sum along a real path (cand = D[u] + w, one rounding per hop),
+// stores only lower a value (64-bit atomicMin on the bit pattern: non-negative doubles order like unsigned integers),
+// and every lowered row is pushed again before the solve ends (it sits in the near list or the far pile until then).
+// The state at termination -- no near work, no far pile, in any batch -- is therefore the same unique fixed point
+// min_u fl(D[u] + w) that Dijkstra computes; the order of pushes and the choice of delta only change the work.
+//
+// State per batch b (16 sources, dist[b][node][16] as in the chunked solve), all in the caller's workspace:
+//   near[parity][b][.]  rows to push this sweep / next sweep, near_cnt ring of 3 (consume, build, clear)
+//   far[ring of 3][b][.] the far pile; a release sweep (near empty) compacts it into the next ring slot
+//   near_stamp[b][v] = sweep for which v is already queued, far_flag[b][v] = 1 while v sits in the pile (dedupe)
+//   theta[parity][b], far_slot[parity][b]: written by the batch's first block for the next sweep.
+// Every block of a batch derives the same decision (push / release / idle) from the counts the previous launch left.
+struct PushState {
+    int32_t *near_lists, *near_cnt, *far_lists, *far_cnt, *far_slot, *near_stamp, *far_flag, *active;
+    double *theta;
+    int32_t cs;          // row stride of the per-batch rings (multiple of 32 ints: a 128-byte line of their own)
+};
+
+__device__ __forceinline__ double slot_min16(double x) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) x = fmin(x, __shfl_xor(x, off, 16));
+    return x;
+}
+
+// queue the rows named by the slot's lanes (lane = one edge's far end `v`, `want` = it was lowered): dedupe through the
+// stamp / flag word (lanes in parallel), then ONE counter atomic per list and slot, entries written at base + rank
+__device__ __forceinline__ void push_enqueue16(const PushState &st, int32_t b, int32_t n, int32_t v, bool want, bool near,
+                                               int32_t stamp, int32_t *near_out, int32_t c_out, int32_t *far_now,
+                                               int32_t f_now, int lane) {
+    bool first = false;
+    if (want) {
+        if (near) first = atomicExch(&st.near_stamp[(size_t)b * n + v], stamp) != stamp;
+        else first = atomicExch(&st.far_flag[(size_t)b * n + v], 1) == 0;
+    }
+    const int sh = (lane >> 4) * 16;
+    const unsigned nm = (unsigned)((__ballot(first && near) >> sh) & 0xffffull);
+    const unsigned fm = (unsigned)((__ballot(first && !near) >> sh) & 0xffffull);
+    const unsigned below = (1u << (lane & 15)) - 1u;
+    if (nm) {
+        const int leader = __ffs((int)nm) - 1;
+        int32_t base = 0;
+        if ((lane & 15) == leader) base = atomicAdd(&st.near_cnt[c_out * st.cs + b], __popc(nm));
+        base = __shfl(base, leader, 16);
+        if (first && near) near_out[base + __popc(nm & below)] = v;
+    }
+    if (fm) {
+        const int leader = __ffs((int)fm) - 1;
+        int32_t base = 0;
+        if ((lane & 15) == leader) base = atomicAdd(&st.far_cnt[f_now * st.cs + b], __popc(fm));
+        base = __shfl(base, leader, 16);
+        if (first && !near) far_now[base + __popc(fm & below)] = v;
+    }
+}
+
+// Block -> batch: blocks are dealt round-robin over the 8 XCDs, so  batch = xcd + 8 * (..)  keeps ALL blocks of a batch on
+// one XCD: its distance rows, stamps and counters stay in that XCD's L2, where the atomics execute.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                        const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                        int32_t blocks_per_batch, double *dist, PushState st, double delta,
+                                                        int32_t sweep) {
+    const int groups8 = (nb + 7) >> 3;
+    const int q = blockIdx.x >> 3;
+    const int b = (blockIdx.x & 7) + 8 * (q % groups8), xb = q / groups8;
+    const int par = sweep & 1, c_in = sweep % 3, c_out = (sweep + 1) % 3, c_clr = (sweep + 2) % 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.active[c_out] = 0;
+    if (b >= nb) return;
+    const int32_t nn = st.near_cnt[c_in * st.cs + b];
+    const int32_t f_now = st.far_slot[par * st.cs + b];
+    const int32_t nf = st.far_cnt[f_now * st.cs + b];
+    const double th = st.theta[par * st.cs + b];
+    const bool release = nn == 0 && nf > 0;
+    const int32_t f_out = release ? (f_now + 1) % 3 : f_now;
+    const double th_next = release ? th + delta : th;
+    if (xb == 0 && threadIdx.x == 0) {                      // this batch's state for the next sweep
+        st.theta[(par ^ 1) * st.cs + b] = th_next;
+        st.far_slot[(par ^ 1) * st.cs + b] = f_out;
+        st.near_cnt[c_clr * st.cs + b] = 0;
+        if (release) st.far_cnt[((f_now + 2) % 3) * st.cs + b] = 0;
+        if (nn > 0 || nf > 0) st.active[c_in] = 1;
+    }
+    if (nn == 0 && nf == 0) return;                          // this batch has reached its fixed point
+
+    const int lane = threadIdx.x & 63;
+    const unsigned s = lane & 15;
+    const int slot_in_block = threadIdx.x >> 4;
+    const int32_t stride = blocks_per_batch * 16;
+    double *D = dist + (size_t)b * n * 16;
+    unsigned long long *Dbits = reinterpret_cast<unsigned long long *>(D);
+    const int32_t *near_in = st.near_lists + ((size_t)par * nb + b) * n;
+    int32_t *near_out = st.near_lists + ((size_t)(par ^ 1) * nb + b) * n;
+    int32_t *far_now = st.far_lists + ((size_t)f_now * nb + b) * n;
+    const int32_t stamp = sweep + 1;
+
+    if (release) {
+        // theta advanced: rows of the pile that are now near move to the near list, the others to the next ring slot.
+        // Lane j of a slot takes entry i + j of the pile; the row's 16 distances are read by the whole slot in turn.
+        int32_t *far_out = st.far_lists + ((size_t)f_out * nb + b) * n;
+        for (int32_t i0 = (xb * 16 + slot_in_block) * 16; i0 < nf; i0 += stride * 16) {
+            const int32_t mine = i0 + (int32_t)s < nf ? far_now[i0 + s] : -1;
+            double key_mine = inf64();
+            for (int j = 0; j < 16; ++j) {
+                const int32_t v = __shfl(mine, j, 16);
+                if (v < 0) break;                                                   // slot-uniform
+                const double key = slot_min16(D[(unsigned)v * 16u + s]);
+                if ((int)s == j) key_mine = key;
+            }
+            const bool live = mine >= 0;
+            const bool near = live && key_mine < th_next;
+            if (near) st.far_flag[(size_t)b * n + mine] = 0;
+            // near rows: dedupe through the stamp; kept rows stay flagged and are appended to the next ring slot
+            bool first = false;
+            if (near) first = atomicExch(&st.near_stamp[(size_t)b * n + mine], stamp) != stamp;
+            const int sh = (lane >> 4) * 16;
+            const unsigned nm = (unsigned)((__ballot(first) >> sh) & 0xffffull);
+            const unsigned km = (unsigned)((__ballot(live && !near) >> sh) & 0xffffull);
+            const unsigned below = (1u << s) - 1u;
+            if (nm) {
+                const int leader = __ffs((int)nm) - 1;
+                int32_t base = 0;
+                if ((int)s == leader) base = atomicAdd(&st.near_cnt[c_out * st.cs + b], __popc(nm));
+                base = __shfl(base, leader, 16);
+                if (first) near_out[base + __popc(nm & below)] = mine;
+            }
+            if (km) {
+                const int leader = __ffs((int)km) - 1;
+                int32_t base = 0;
+                if ((int)s == leader) base = atomicAdd(&st.far_cnt[f_out * st.cs + b], __popc(km));
+                base = __shfl(base, leader, 16);
+                if (live && !near) far_out[base + __popc(km & below)] = mine;
+            }
+        }
+        return;
+    }
+    // push: a 16-lane slot takes one changed row u and relaxes its edges for the batch's 16 sources
+    for (int32_t i = xb * 16 + slot_in_block; i < nn; i += stride) {
+        const int32_t u = near_in[i];
+        const double du = D[(unsigned)u * 16u + s];
+        const double mu = slot_min16(du);                               // smallest distance of this row over the sources
+        const int32_t e0 = indptr[u], e1 = indptr[u + 1];
+        for (int32_t e = e0; e < e1; e += 16) {
+            const int32_t cnt = e1 - e;
+            const int idx = ((int)s < cnt) ? indices[e + s] : u;         // padding: the row itself at +inf (no effect)
+            const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+            double dv[16];
+            unsigned long long old[16];
+            unsigned off[16];
+            float ww[16];
+#define GEO_PUSH_LOAD(J)                                                                                    \
+    off[J] = ((unsigned)row_bcast<J>(idx) << 7) | (s << 3); ww[J] = __int_as_float(row_bcast<J>(wb));       \
+    dv[J] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(D) + off[J]);
+            GEO_PUSH_LOAD(0) GEO_PUSH_LOAD(1) GEO_PUSH_LOAD(2) GEO_PUSH_LOAD(3) GEO_PUSH_LOAD(4) GEO_PUSH_LOAD(5)
+            GEO_PUSH_LOAD(6) GEO_PUSH_LOAD(7) GEO_PUSH_LOAD(8) GEO_PUSH_LOAD(9) GEO_PUSH_LOAD(10) GEO_PUSH_LOAD(11)
+            GEO_PUSH_LOAD(12) GEO_PUSH_LOAD(13) GEO_PUSH_LOAD(14) GEO_PUSH_LOAD(15)
+#undef GEO_PUSH_LOAD
+            // all minima of the chunk are issued before any result is looked at (16 atomics in flight, not 16 round trips)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double cand = du + (double)ww[j];
+                old[j] = 0ull;
+                if (cand < dv[j])
+                    old[j] = atomicMin(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(Dbits) + off[j]),
+                                       (unsigned long long)__double_as_longlong(cand));
+            }
+            unsigned movedmask = 0u;                                     // bit j: some source of the slot lowered edge j's far end
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double cand = du + (double)ww[j];
+                const bool better = old[j] > (unsigned long long)__double_as_longlong(cand);
+                if ((__ballot(better) >> ((lane >> 4) * 16)) & 0xffffull) movedmask |= 1u << j;
+            }
+            if (movedmask)                                               // lane s speaks for edge s of the chunk
+                push_enqueue16(st, b, n, idx, (movedmask >> s) & 1u, mu + (double)__int_as_float(wb) < th, stamp, near_out,
+                               c_out, far_now, f_now, lane);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void push_init_kernel(const int32_t *__restrict__ src_pad, int32_t n, int32_t nb, PushState st,
+                                                       double delta) {
+    // one block per batch: near list = the batch's distinct sources, everything else empty
+    const int b = blockIdx.x;
+    if (threadIdx.x < 3) {
+        st.near_cnt[threadIdx.x * st.cs + b] = 0;
+        st.far_cnt[threadIdx.x * st.cs + b] = 0;
+    }
+    if (threadIdx.x < 2) {
+        st.theta[threadIdx.x * st.cs + b] = delta;
+        st.far_slot[threadIdx.x * st.cs + b] = 0;
+    }
+    if (b == 0 && threadIdx.x < 3) st.active[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int32_t v = src_pad[b * 16 + threadIdx.x];
+        if (v >= 0 && v < n && atomicExch(&st.near_stamp[(size_t)b * n + v], 0x7fffffff) != 0x7fffffff)
+            st.near_lists[(size_t)b * n + atomicAdd(&st.near_cnt[b], 1)] = v;          // parity 0, ring slot 0 = sweep 0
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict__ w, int64_t nnz, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) acc += (double)w[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+size_t push_bytes(int32_t n, int32_t nb) {
+    const size_t cs = ((size_t)nb + 31) / 32 * 32, per = (size_t)nb * n;
+    return geo::align_up(2 * per * 4) + geo::align_up(3 * per * 4) + 2 * geo::align_up(per * 4) + geo::align_up(3 * cs * 4) * 2 +
+           geo::align_up(2 * cs * 4) + geo::align_up(2 * cs * 8) + 512 + 256;
+}
+
 __device__ __forceinline__ double units_to_f64(uint32_t u, double unit) { return u == U_INF ? inf64() : (double)u * unit; }
 
 // any distance that saturated?  (checked once, at the fixed point)
@@ -763,10 +986,15 @@ struct MultiWs {
 // N=60 000, but its per-lane addressing and four CSR rows per wave cost more than the L2 hits return
 // (7-10 TB/s of gathered bytes against 9-19 TB/s).  16 is kept for calls with few sources, where it
 // avoids relaxing padded lanes.
+// The 16- and 32-source row kernels form gather addresses as 32-bit BYTE offsets from a batch's base (node << 7 | ...):
+// a batch of n nodes spans n * 128 bytes, so these layouts exist only below 2^25 nodes.
+constexpr int32_t ROW128_MAX_NODES = 1 << 25;
+
 int choose_sb(int32_t n, int32_t n_sources, int forced_here) {
     const int forced = forced_here ? forced_here : geo::options().sssp_sb;   // (option: experiment switch)
     if (forced == 16 || forced == 64) return forced;
     if (n_sources <= 16) return 16;
+    if (n >= ROW128_MAX_NODES) return 64;                                    // 64-bit indexing only (sweep_multi_kernel)
     if (n_sources >= 32 && (size_t)n * 512 > ((size_t)6 << 20)) {
         // 16-source batches pay off while one batch (n * 128 bytes) stays within reach of an XCD's 4 MiB L2 ...
         if ((size_t)n * 128 <= ((size_t)12 << 20)) return 16;
@@ -783,7 +1011,7 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
            geo::align_up(4 * (((size_t)nb + 31) / 32 * 32) * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) +
-           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024;
+           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024 + push_bytes(n, nb);
 }
 
 // slots of a solve: whole batches of `sb` sources, and (for the 32-source fixed-point layout of the same buffers) of 32
@@ -821,7 +1049,8 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     GEO_REQUIRE(indptr && indices && sources && ws, "geo_sssp_multi: null pointer");
     const int sb = choose_sb(n, n_sources, force_sb);
     const int32_t nb = (n_sources + sb - 1) / sb;
-    const bool chunked = sb == 16 && n_sources > 16;       // 16-edge chunk work items (see sweep_chunk16_kernel)
+    // 16-edge chunk work items (see sweep_chunk16_kernel); their 32-bit row offsets need n * 128 bytes < 2^32
+    const bool chunked = sb == 16 && n_sources > 16 && n < ROW128_MAX_NODES;
     GEO_REQUIRE(nnz >= 0, "geo_sssp_multi: nnz must be given");
     if (ws_bytes < multi_bytes(n, nb, sb, P_out != nullptr) + (chunked ? chunk_bytes(n, nnz, nb) : 0)) {
         geo::set_error("geo_sssp_multi: workspace %zu < %zu", ws_bytes,
@@ -848,6 +1077,8 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     int32_t *lm_flags = nullptr;
     uint32_t *wunits = nullptr, *wrange = nullptr;           // 32-bit fixed-point weights / their range
     int32_t *chunk_cnt = nullptr, *row_order = nullptr;
+    PushState push{};
+    double *wsum = nullptr;
     const geo::Options &opt = geo::options();
     const int act_mode = opt.sssp_act;
     // sparse body while fewer than n/sparse_div rows moved in the previous sweep; map kept below n/map_div
@@ -873,7 +1104,21 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         lm_flags = ar.take<int32_t>(16);                    // [0..3] solve flags, [8..9] the landmark eccentricity (u64)
         wunits = ar.take<uint32_t>((size_t)(nnz > 0 ? nnz : 1));
         wrange = ar.take<uint32_t>(4);
-        GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange,
+        const size_t per = (size_t)nb * n;
+        push.cs = cs;
+        push.near_lists = ar.take<int32_t>(2 * per);
+        push.far_lists = ar.take<int32_t>(3 * per);
+        push.near_stamp = ar.take<int32_t>(per);
+        push.far_flag = ar.take<int32_t>(per);
+        push.near_cnt = ar.take<int32_t>(3 * (size_t)cs);
+        push.far_cnt = ar.take<int32_t>(3 * (size_t)cs);
+        push.far_slot = ar.take<int32_t>(2 * (size_t)cs);
+        push.theta = ar.take<double>(2 * (size_t)cs);
+        push.active = ar.take<int32_t>(64);
+        wsum = ar.take<double>(8);
+        GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange && push.near_lists &&
+                        push.far_lists && push.near_stamp && push.far_flag && push.near_cnt && push.far_cnt && push.far_slot &&
+                        push.theta && push.active && wsum,
                     "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
@@ -946,7 +1191,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     };
     g_last_sweep_ms = 0.0;
     // ---- exact 32-bit fixed-point solve (32 sources per row) when the weights qualify; see sweep_chunk32u_kernel ----
-    if (chunked && n_sources >= 32 && opt.sssp_u32 != 0) {
+    if (chunked && n_sources >= 32 && opt.sssp_u32 != 0 && opt.sssp_push != 2) {
         int shift = 0;
         bool eligible = true;
         if (weights) {
@@ -1042,6 +1287,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                         // some node is landmark_ecc away from sources[0]: if that alone does not fit 32 bits of units the
                         // fixed-point solve would only find out at its end -- the fp64 kernels take the (ordered) sources now
                         if (landmark_ecc / unit >= 4294967294.0) give_up = true;
+                        if (opt.sssp_push == 3) give_up = true;        // (experiment: ordered sources always take the push solve)
                     }
                 }
                 if (!done && sweeps > (int64_t)n + 2) give_up = true;
@@ -1082,6 +1328,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                                    argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }
     int32_t total_sweeps = 0;
+    bool pushed = false;
     // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
     // sources moved a neighbour, so with 16 scattered sources every row is re-evaluated as each of 16 fronts
     // passes (and their corrections cascade), with 16 neighbouring sources the fronts pass as one.  On graphs
@@ -1103,6 +1350,60 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
             source_need_kernel<<<geo::grid_for((int64_t)n_sources * 16, 256, 256), 256, 0, stream>>>(
                 w.src_pad, n_sources, n, sb, words, indptr, indices, bits + 2 * (size_t)nb * words);
             GEO_LAUNCH_CHECK();
+        }
+        if (chunked && opt.sssp_push != 0 && (grouped || opt.sssp_push == 2 || group_mode == 2)) {
+            // ---- long geodesics: near-far push solve (see push_sweep_kernel) ----
+            double mean_w = 1.0;
+            if (weights && nnz > 0) {
+                GEO_HIP_CHECK(hipMemsetAsync(wsum, 0, sizeof(double), stream));
+                weight_sum_kernel<<<geo::grid_for(nnz, 256, 1024), 256, 0, stream>>>(weights, nnz, wsum);
+                GEO_HIP_CHECK(hipMemcpyAsync(&mean_w, wsum, sizeof(double), hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                mean_w /= (double)nnz;
+            }
+            const double delta = (opt.sssp_delta > 0 ? (double)opt.sssp_delta : 4.0) * (mean_w > 0.0 ? mean_w : 1.0);
+            const size_t per = (size_t)nb * n;
+            GEO_HIP_CHECK(hipMemsetAsync(push.near_stamp, 0, per * 4, stream));
+            GEO_HIP_CHECK(hipMemsetAsync(push.far_flag, 0, per * 4, stream));
+            push_init_kernel<<<nb, 256, 0, stream>>>(w.src_pad, n, nb, push, delta);
+            GEO_LAUNCH_CHECK();
+            const int bpb = opt.sssp_push_blocks > 0 ? opt.sssp_push_blocks : 64;
+            const unsigned pgrid = (unsigned)(((nb + 7) / 8) * 8) * (unsigned)bpb;        // batch <-> XCD: see push_sweep_kernel
+            int32_t sweeps = 0, hact = 1;
+            const int64_t plimit = 64 * (int64_t)n + 64;
+            int group_len = 8;
+            while (hact) {
+                int last = 0;
+                GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
+                for (int g = 0; g < group_len; ++g, ++sweeps) {
+                    if (weights) push_sweep_kernel<true><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, bpb, w.dist, push, delta, sweeps);
+                    else push_sweep_kernel<false><<<pgrid, 256, 0, stream>>>(indptr, indices, weights, n, nb, bpb, w.dist, push, delta, sweeps);
+                    GEO_LAUNCH_CHECK();
+                    if (opt.sssp_trace) {
+                        std::vector<int32_t> hn(cs), hfc(3 * (size_t)cs);
+                        GEO_HIP_CHECK(hipMemcpy(hn.data(), push.near_cnt + (size_t)((sweeps + 1) % 3) * cs, (size_t)cs * 4, hipMemcpyDeviceToHost));
+                        GEO_HIP_CHECK(hipMemcpy(hfc.data(), push.far_cnt, 3 * (size_t)cs * 4, hipMemcpyDeviceToHost));
+                        long long tn = 0, tf = 0, idle = 0;
+                        for (int32_t b = 0; b < nb; ++b) { tn += hn[b]; long long f = std::max(hfc[b], std::max(hfc[cs + b], hfc[2 * cs + b])); tf += f; idle += (hn[b] == 0 && f == 0); }
+                        fprintf(stderr, "[sssp-push] sweep %d: next near %lld, far pile <= %lld, idle batches %lld/%d\n", sweeps, tn, tf, idle, nb);
+                    }
+                    last = sweeps % 3;
+                }
+                GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
+                GEO_HIP_CHECK(hipMemcpyAsync(&hact, push.active + last, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                float ms = 0.f;
+                GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+                g_last_sweep_ms += ms;
+                if (hact && sweeps > plimit) {
+                    geo::set_error("geo_sssp_multi: near-far solve did not finish within %d sweeps", sweeps);
+                    return GEO_E_NOCONV;
+                }
+                if (sweeps >= 32 && group_len < 32) group_len *= 2;
+            }
+            total_sweeps += sweeps;
+            pushed = true;
+            break;
         }
         // grouped solves run many sweeps that touch few rows: a smaller grid keeps the idle launches cheap
         const int want_cap = opt.sssp_grouped_cap;
@@ -1188,7 +1489,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     const int32_t sweeps = total_sweeps;
     if (sweeps_out) *sweeps_out = sweeps;
     g_last_sweep_launches = sweeps;
-    g_last_layout = sb + (chunked ? 1000 : 0);
+    g_last_layout = sb + (chunked ? 1000 : 0) + (pushed ? 3000 : 0);          // 4016 = near-far push solve
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {
@@ -1220,6 +1521,14 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                               int32_t *sweeps_out, void *stream_) {
     return sssp_multi_impl(indptr, indices, weights, n, nnz, sources, n_sources, D_out, P_out, dmin_out, argmin_out, ws,
                            ws_bytes, sweeps_out, stream_, 0);
+}
+
+extern "C" int geo_sssp_plan(int32_t n, int32_t n_sources) {
+    if (n <= 0 || n_sources <= 0) return GEO_E_ARG;
+    const int sb = choose_sb(n, n_sources, 0);
+    const bool chunked = sb == 16 && n_sources > 16 && n < ROW128_MAX_NODES;
+    const bool u32 = chunked && n_sources >= 32 && geo::options().sssp_u32 != 0;
+    return sb + (chunked ? 1000 : 0) + (u32 ? 2000 : 0);
 }
 
 extern "C" int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches) {

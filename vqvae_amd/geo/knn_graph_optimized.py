@@ -99,6 +99,25 @@ def _generic_metric_search(z: torch.Tensor, n_neighbors: int, metric: str):
     return idx_out, d_out
 
 
+def _cosine_search_with_zero_rows(unit: torch.Tensor, n_neighbors: int):
+    """Cosine search when some latent is exactly zero.  sklearn (cosine_distances behind knn_graph_optimized.py:40) leaves
+    a zero row un-normalised, so its similarity to EVERY row is 0 and its distance 1.0 -- not the |x^ - y^|^2 / 2 = 0.5
+    the unit-row Euclidean search would give.  Rare, so no kernel: 1 - <x^, y^> blockwise in fp64 on the GPU, clipped to
+    [0, 2], self-distance 0, ranked by (distance, index).  Returns (idx int32, distance f64) including self."""
+    N = unit.shape[0]
+    idx_out = torch.empty((N, n_neighbors), dtype=torch.int32, device=unit.device)
+    d_out = torch.empty((N, n_neighbors), dtype=torch.float64, device=unit.device)
+    step = max(1, min(N, (1 << 27) // max(1, N)))
+    for r0 in range(0, N, step):
+        D = (1.0 - unit[r0:r0 + step] @ unit.T).clamp_(0.0, 2.0)
+        rows = torch.arange(r0, min(r0 + step, N), device=unit.device)
+        D[rows - r0, rows] = 0.0
+        vals, order = torch.sort(D, dim=1, stable=True)
+        idx_out[r0:r0 + step] = order[:, :n_neighbors].to(torch.int32)
+        d_out[r0:r0 + step] = vals[:, :n_neighbors]
+    return idx_out, d_out
+
+
 def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str = "mutual", group=None,
                      need_dist: bool = True, metric: str = "euclidean"):
     """Resident latents -> (DeviceCSR, distances f64 [N,k'] | None, indices int32 [N,k']); k' = min(k, N-1) >= 1.
@@ -114,7 +133,13 @@ def knn_graph_device(z: torch.Tensor, k: int, mode: str = "distance", sym: str =
         # csrc/knn.hip on the normalised latents ranks exactly by it (sklearn: cosine_distances, clipped to [0, 2])
         z64 = z.to(torch.float64)
         nrm = torch.linalg.vector_norm(z64, dim=1, keepdim=True)
-        z = (z64 / torch.where(nrm == 0, torch.ones_like(nrm), nrm)).to(torch.float32).contiguous()
+        unit64 = z64 / torch.where(nrm == 0, torch.ones_like(nrm), nrm)
+        if bool((nrm == 0).any()):                     # a zero latent is at cosine distance 1 from everything
+            idx, dist = _cosine_search_with_zero_rows(unit64, min(k_eff + 1, N))
+            dist, idx = _drop_self(dist, idx)
+            weights = dist.to(torch.float32).contiguous() if mode == "distance" else None
+            return symmetrize_device(idx, weights, sym), dist, idx
+        z = unit64.to(torch.float32).contiguous()
     elif metric != "euclidean":
         idx, dist = _generic_metric_search(z, min(k_eff + 1, N), metric)
         dist, idx = _drop_self(dist, idx)
@@ -234,19 +259,75 @@ def build_knn_graph_sklearn(z: np.ndarray, k: int = 10, metric: str = "euclidean
     return G.to_scipy(), info
 
 
+def _faiss_style_graph(idx: torch.Tensor, dist32: torch.Tensor, mode: str, sym: str):
+    """knn_graph_optimized.py:102-124: drop column 0 only if it is the row itself in EVERY row, CSR from the remaining
+    columns (squared distances or ones), mutual / union, zero diagonal, explicit zeros removed."""
+    N = idx.shape[0]
+    me = torch.arange(N, device=idx.device, dtype=idx.dtype)
+    if idx.shape[1] > 1 and bool((idx[:, 0] == me).all()):
+        idx, dist32 = idx[:, 1:].contiguous(), dist32[:, 1:].contiguous()
+    weights = dist32.contiguous() if mode == "distance" else None
+    return symmetrize_device(idx.contiguous(), weights, sym), dist32, idx
+
+
 def build_knn_graph_faiss(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
-                          sym: str = "mutual"):
-    """FAISS is not part of this build; same error the reference raises without it (knn_graph_optimized.py:73-74)."""
-    raise RuntimeError("FAISS not available, falling back to sklearn")
+                          sym: str = "mutual") -> Tuple[sparse.csr_matrix, Dict[str, np.ndarray]]:
+    """The reference's FAISS branch (knn_graph_optimized.py:70-126) WITHOUT FAISS: its semantics on the HIP search.
+    What differs from the sklearn branch and is reproduced here: `euclidean` weights / info["distances"] are SQUARED L2
+    distances in float32 (IndexFlatL2.search), `cosine` = 1 - <x^, y^> with x^ = x / (|x| + 1e-8) in float32
+    (IndexFlatIP), the self column is dropped only when it leads every row, there is no k = 0 / N = 1 special case, and
+    any other metric raises ValueError.  Neighbours are ranked by the exact fp64 distance (FAISS ranks by a float32
+    ||x||^2 - 2 x.y + ||y||^2: the two orders differ only between candidates closer than float32 rounding).
+    PARITY UNPINNED: FAISS is not installed in the build container, so no fixture of the reference's FAISS output
+    exists; tests compare with a numpy restatement of the published IndexFlat algorithm (oracle/knn.py)."""
+    if not FAISS_SEMANTICS:          # the reference without FAISS installed (knn_graph_optimized.py:73-74): the pinned default
+        raise RuntimeError("FAISS not available, falling back to sklearn")
+    assert z.ndim == 2, "z must be (N,D)"
+    if metric not in ("euclidean", "cosine"):
+        raise ValueError(f"FAISS metric '{metric}' not supported. Use 'euclidean' or 'cosine'.")
+    if sym not in _SYM_MODE:
+        raise ValueError(f"Invalid symmetry mode: {sym}")
+    N = z.shape[0]
+    dev = device()
+    z32 = np.ascontiguousarray(z, dtype=np.float32)
+    if metric == "cosine":
+        z32 = np.ascontiguousarray((z / (np.linalg.norm(z, axis=1, keepdims=True) + 1e-8)).astype(np.float32))
+    z_dev = torch.from_numpy(z32).to(dev)
+    idx, d2 = knn_search_device(z_dev, min(k + 1, N))
+    if metric == "euclidean":
+        dist32 = d2.to(torch.float32)
+    else:       # inner product of the float32 rows from the exact squared distance: <x, y> = (|x|^2 + |y|^2 - |x - y|^2) / 2
+        sq = (z_dev.double() ** 2).sum(dim=1)
+        ip = 0.5 * (sq[:, None] + sq[idx.long()] - d2)
+        dist32 = (1.0 - ip.to(torch.float32)).to(torch.float32)
+    G, dist32, idx = _faiss_style_graph(idx, dist32, mode, sym)
+    return G.to_scipy(), {"distances": dist32.cpu().numpy(), "indices": idx.cpu().numpy().astype(np.int64)}
+
+
+# False (default): behave like the reference WITHOUT faiss installed -- the FAISS entry points raise its RuntimeErrors.
+# True: behave like a reference WITH faiss: build_knn_graph_faiss answers, build_knn_graph_auto picks it for N >= threshold.
+FAISS_SEMANTICS = False
 
 
 def build_knn_graph_auto(z: np.ndarray, k: int = 10, metric: str = "euclidean", mode: str = "distance",
                          sym: str = "mutual", force_method: Optional[str] = None, size_threshold: int = 50000):
-    """Method selection kept for signature compatibility (knn_graph_optimized.py:129-170); every size runs the
-    exact HIP brute force."""
-    if force_method == "faiss":
-        raise RuntimeError("force_method='faiss' but FAISS not available")
-    print(f"Building k-NN graph: N={z.shape[0]}, k={k}, method=hip")
+    """Method selection of knn_graph_optimized.py:129-170.  Every search is the exact HIP brute force; `method` only
+    selects the SEMANTICS: "sklearn" (true distances, fp64-ranked: pinned by fixtures) or "faiss" (squared float32
+    distances etc., see build_knn_graph_faiss: unpinned).  Without FAISS the reference always takes the sklearn branch,
+    which is the default here too (force_method="faiss" raises as it does there); FAISS_SEMANTICS = True opts into the
+    behaviour of a reference that has FAISS."""
+    N = z.shape[0]
+    if force_method == "sklearn":
+        method = "sklearn"
+    elif force_method == "faiss":
+        if not FAISS_SEMANTICS:
+            raise RuntimeError("force_method='faiss' but FAISS not available")
+        method = "faiss"
+    else:
+        method = "faiss" if (FAISS_SEMANTICS and N >= size_threshold) else "sklearn"
+    print(f"Building k-NN graph: N={N}, k={k}, method={method if method == 'faiss' else 'hip'}")
+    if method == "faiss":
+        return build_knn_graph_faiss(z, k=k, metric=metric, mode=mode, sym=sym)
     return build_knn_graph_sklearn(z, k=k, metric=metric, mode=mode, sym=sym)
 
 

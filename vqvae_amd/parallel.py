@@ -97,6 +97,55 @@ def sharded_edge_lengths(n_edges: int, batch_size: int, length_fn: Callable, gro
     return all_gather_rows(local, counts, group)
 
 
+class RunningStatFold:
+    """BatchNorm running statistics of a train-mode decoder when the JVP chunks are sharded over ranks.
+
+    torch folds every decoder call into the buffers in order, r <- (1 - m) r + m s_t (riemannian_metric.py:57-58: two
+    calls per chunk).  That recurrence is linear, so a rank that starts its block from ZERO buffers ends with
+    sum_t m (1 - m)^(T_b - 1 - t) s_t over ITS calls, and the single-process result is
+        (1 - m)^T r_0 + sum_b (1 - m)^(calls after block b) * fold_b .
+    `start()` zeroes this rank's buffers (remembering r_0), `finish()` all-gathers the per-rank folds and writes the
+    combination back, so every rank -- and a checkpoint saved by any of them -- holds the same buffers, equal to the
+    single-process ones up to float32 rounding of the re-associated sum; `num_batches_tracked` advances by the calls of
+    ALL ranks."""
+
+    KEYS = ("rm1", "rv1", "rm2", "rv2")
+
+    def __init__(self, export, group=None):
+        self.export, self.group = export, group
+        self.rank, self.world = world_info(group)
+        self.active = self.world > 1 and export.tracks_running
+        self.r0 = None
+
+    def start(self) -> None:
+        if not self.active:
+            return
+        self.r0 = torch.cat([self.export.tensors[k].flatten() for k in self.KEYS]).double()
+        for k in self.KEYS:
+            self.export.tensors[k].zero_()
+
+    def finish(self, n_edges: int, batch_size: int) -> None:
+        if not self.active:
+            return
+        calls = []
+        for r in range(self.world):
+            a, b = chunk_range(n_edges, batch_size, r, self.world)
+            calls.append(2 * ((b - a + batch_size - 1) // batch_size))
+        mine = torch.cat([self.export.tensors[k].flatten() for k in self.KEYS]).contiguous()
+        folds = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(folds.view(-1), mine, group=self.group)
+        keep = 1.0 - float(self.export.desc.momentum)
+        total = self.r0 * keep ** sum(calls)
+        for r in range(self.world):
+            total = total + folds[r].double() * keep ** sum(calls[r + 1:])
+        off = 0
+        for k in self.KEYS:
+            t = self.export.tensors[k]
+            t.copy_(total[off:off + t.numel()].view_as(t).to(t.dtype))
+            off += t.numel()
+        self.export.commit_running_stats(sum(calls) - calls[self.rank])      # copies back, counts the other ranks' calls
+
+
 def merge_min_argmin(dmin: torch.Tensor, arg: torch.Tensor, offsets: List[int], group=None):
     """Per-rank (column minimum, first local row attaining it) over disjoint source blocks -> the global
     (minimum, first row) with numpy's argmin tie rule: lowest global row index among equal minima;

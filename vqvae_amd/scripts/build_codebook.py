@@ -25,7 +25,7 @@ from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, knn_graph_device, lcc_mask_device, reweight_device,
                                        upper_edges_device)
 from ..geo.riemannian_metric import edge_lengths_graph_device, edge_lengths_riemannian
-from ..parallel import sharded_edge_lengths, world_info
+from ..parallel import RunningStatFold, sharded_edge_lengths, world_info
 from ..spatial_decoder import DecoderExport, hip_kernels_cover, load_decoder_from_checkpoint
 
 
@@ -54,10 +54,13 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
     sharded = {"knn": world > 1, "jvp": world > 1 and hip_kernels_cover(decoder)}   # what the ranks really split
     if hip_kernels_cover(decoder):
         export = DecoderExport(decoder, dev)
+        fold = RunningStatFold(export, group)           # multi-rank: BatchNorm running statistics as one process leaves them
+        fold.start()
         # whole chunks of `batch_size` edges per rank: every BatchNorm batch stays intact
         lengths = sharded_edge_lengths(
             int(src.numel()), batch_size,
             lambda e0, e1: edge_lengths_graph_device(export, z_flat, src[e0:e1], dst[e0:e1], batch_size), group)
+        fold.finish(int(src.numel()), batch_size)
     else:       # e.g. GroupNorm: no kernel, autograd on the GPU (the reference's own method)
         lengths = edge_lengths_riemannian(decoder, z_flat[src.long()], z_flat[dst.long()], batch_size).contiguous()
     t0 = tick("jvp", t0)
