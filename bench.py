@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- latents/s through the geodesic-codebook hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss|real|c5cb]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss|real|c5cb|c5prior]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU
@@ -54,6 +54,7 @@ WORKLOADS = {
     # the shapes the reference's pipeline really feeds build_codebook.py (SURVEY finding 7: N*H*W nodes, build_codebook.py:35):
     "real": (960000, 16, 1, 28, 20, 512),       # FashionMNIST: 60 000 images x 4x4 cells, d=16, K=512
     "c5cb": (800000, 32, 3, 32, 20, 512),       # CIFAR-10 (BASELINE config 5's codebook stage): 50 000 x 4x4 cells, d=32, 32-px decoder
+    "c5prior": None,                            # BASELINE config 5's second stage: prior training tokens/s (prior_bench)
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak = half the 157.3 TFLOP/s f32 vector peak of MI355X_MICROARCH.md
@@ -131,7 +132,7 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
         ms_, launches_ = np.zeros(1, np.float64), np.zeros(1, np.int32)
         layout = _lib.load().geo_sssp_last_profile(ms_.ctypes.data, launches_.ctypes.data)
         prof["ms"], prof["launches"], prof["sources"] = float(ms_[0]), int(launches_[0]), s1 - s0
-        prof["kernel"] = ("push_sweep_kernel" if layout >= 4000 else "sweep_chunk32u_kernel" if layout >= 2000
+        prof["kernel"] = ("push_persistent_kernel" if layout >= 5000 else "push_sweep_kernel" if layout >= 4000 else "sweep_chunk32u_kernel" if layout >= 2000
                           else "sweep_chunk16_kernel" if layout >= 1000
                           else f"sweep_multi_kernel<{layout}>")
         return dmin_, arg_
@@ -195,6 +196,97 @@ def cpu_baseline(res, z, dec, cfg, full):
     return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "host_logical_cpus": os.cpu_count(), "sample": sample,
             "stages_s": {"knn": round(t_knn, 3), "jvp": round(t_jvp, 3), "kmedoids": round(t_kmed, 3)}}
+
+
+def prior_bench(args, rank, world, dev, json_fd):
+    """Secondary line (--workload c5prior): training throughput of the code prior at BASELINE config 5's shape -- the
+    reference's configs/cifar10/spatial/geodesic/transformer.yaml model (4 layers, 256 dims, 4 heads, 512 tokens, dropout 0.1),
+    batch 256 of 15-token sequences, AdamW -- on synthetic codes.  One step = forward + backward + (all-reduce) + optimiser.
+    Timed twice: the MI355X-native step (HIP-graph replay, fused attention kernels, one-launch AdamW) and the same step on
+    stock torch ops, both in this process."""
+    import torch.nn.functional as F
+    from vqvae_amd.parallel import block_range
+    from vqvae_amd.prior.native import ArenaAdamW, GraphedStep
+    from vqvae_amd.prior.transformer import Transformer
+    K, B, T = 512, 256, 16
+    torch.manual_seed(0)
+    cfg = dict(num_classes=10, num_tokens=K, embed_dim=256, n_layers=4, n_head=4, max_seq_len=T, dropout=0.1)
+    tokens = torch.randint(0, K, (50000, T), device=dev)
+    labels_all = torch.randint(0, 10, (50000,), device=dev)
+    lo, hi = block_range(B, rank, world)
+
+    def run(native):
+        torch.manual_seed(1)
+        model = Transformer(**cfg).to(dev).train()
+        model.fused_attention = native
+        model.arena.grad = torch.zeros_like(model.arena)
+        opt = ArenaAdamW(model.arena, 3e-4, 0.01) if native else torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=0.01)
+
+        def loss_fn(x, y, lab):
+            logits = model(x, y=lab)
+            return F.cross_entropy(logits.reshape(-1, K), y.reshape(-1), reduction="sum") / (B * (T - 1))
+
+        graphed = None
+        g = torch.Generator(device="cpu").manual_seed(2)
+
+        def step():
+            nonlocal graphed
+            pick = torch.randint(0, 50000, (B,), generator=g)[lo:hi].to(dev)
+            rows = tokens[pick]
+            x, y, lab = rows[:, :-1], rows[:, 1:], labels_all[pick]
+            if native:
+                if graphed is None:
+                    graphed = GraphedStep(model, loss_fn, x.contiguous(), y.contiguous(), lab)
+                loss = graphed.run(x, y, lab)
+            else:
+                model.arena.grad.zero_()
+                loss = loss_fn(x, y, lab)
+                loss.backward()
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(model.arena.grad)
+            opt.step()
+            return loss
+
+        for _ in range(max(args.warmup, 3)):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, float(last)
+
+    with contextlib.redirect_stdout(sys.stderr):
+        dt_native, loss_native = run(True)
+        dt_eager, loss_eager = run(False)
+    tok = B * (T - 1) * args.steps
+    out = {"metric": "prior training tokens/sec (BASELINE config 5's second stage; secondary to the codebook metric)",
+           "value": tok / dt_native, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3),
+           "ms_per_step": dt_native / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "c5prior: Transformer 4 layers x 256 dims x 4 heads, 512 tokens, 15-token sequences, global batch 256, "
+                                  "dropout 0.1, AdamW lr 3e-4 wd 0.01", "parallelism": f"{world} rank(s), batch split, one flat all-reduce of 13 MB"},
+           "native": {"what": "HIP-graph forward+backward, fused attention (csrc/prior.hip), one-launch AdamW", "ms_per_step": dt_native / args.steps * 1e3,
+                      "last_loss": loss_native},
+           "eager_torch": {"what": "same model and step on stock torch ops (the reference's method)", "ms_per_step": dt_eager / args.steps * 1e3,
+                           "tokens_per_s": tok / dt_eager, "last_loss": loss_eager},
+           "speedup_over_eager": dt_eager / dt_native}
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def free_port() -> int:
@@ -261,6 +353,12 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    if args.workload == "c5prior":
+        prior_bench(args, rank, world, dev, json_fd)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     z, dec, cfg = make_inputs(args.workload, dev)
     timers, prof, res = {}, (0.0, 0), None
     with contextlib.redirect_stdout(sys.stderr):

@@ -71,7 +71,9 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
  * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
  * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel,
  * 2032 for the exact 32-bit fixed-point kernel (32 sources per row), 4016 for the near-far push solve
- * (long geodesics: sources ordered along landmark distances, 16 per batch, delta-stepping buckets). */
+ * (long geodesics: sources ordered along landmark distances, 16 per batch, delta-stepping buckets) with one launch per
+ * sweep, 5016 for the same solve run to its end inside ONE launch by a team of workgroups per XCD (then
+ * *sweep_launches = 1 and *sweep_ms is that launch). */
 int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
 
 /* The layout geo_sssp_multi would START with for a graph of n nodes and n_sources sources (host arithmetic only, no GPU
@@ -252,6 +254,23 @@ int geo_decoder_jvp_pairs(const geo_decoder_desc *dec, const float *z_start, con
 
 /* Gather: data_out[e] = len[entry_edge[e]] for every stored entry (W_geo = U + U^T). */
 int geo_gather_edge_weights(const float *len, const int32_t *entry_edge, int64_t nnz, float *data_out, void *stream);
+
+/* ---- the code prior's training step (src/models/transformer.py:98-133, src/scripts/train_transformer.py:39-66) ----
+ * Fused causal multi-head attention for sequences of at most 16 tokens.  qkv f32 [B][T][3][H][head_dim] (the c_attn
+ * projection's output), head_dim in {16, 32, 64}; out f32 [B][T][H*head_dim]; probs f32 [B][H][T][T] receives the softmax
+ * rows (kept for the backward pass); keep u8 [B][H][T][T] (1 = kept) or NULL applies dropout to them with
+ * keep_scale = 1 / (1 - p).  Replaces q @ k^T * scale -> masked_fill(-inf) -> softmax -> dropout -> @ v
+ * (transformer.py:121-129).  Asynchronous on `stream`. */
+int geo_prior_attention_fwd(const float *qkv, const uint8_t *keep, float keep_scale, int32_t B, int32_t T, int32_t H,
+                            int32_t head_dim, float *out, float *probs, void *stream);
+/* Gradient of the above with respect to qkv: dqkv f32 [B][T][3][H][head_dim] from dout f32 [B][T][H*head_dim]. */
+int geo_prior_attention_bwd(const float *qkv, const float *probs, const uint8_t *keep, float keep_scale, const float *dout,
+                            int32_t B, int32_t T, int32_t H, int32_t head_dim, float *dqkv, void *stream);
+/* torch.optim.AdamW's update (train_transformer.py:39-43,64-66: decoupled weight decay, bias-corrected moments) over ONE
+ * flat buffer of n floats in a single pass.  lr_dev f32 [1] and step_dev i64 [1] (the 1-based step count of THIS update) are
+ * read on the device, so the launch does not change from step to step.  Asynchronous on `stream`. */
+int geo_prior_adamw(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
+                    const int64_t *step_dev, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -352,7 +352,7 @@ def test_cosine_graph_with_a_zero_latent_follows_sklearn(golden):
     W, info = build_knn_graph_auto(z, k=10, metric="cosine", mode="distance", sym="union")
     rows = g["rows"]
     np.testing.assert_array_equal(info["indices"][rows], g["nbr_indices"])
-    np.testing.assert_allclose(info["distances"][rows], g["nbr_distances"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(info["distances"][rows], g["nbr_distances"], rtol=0, atol=3e-7)     # f32 cosine: 1 ulp near 1
     assert not (info["indices"][rows] == 17).any()                       # nobody is near the zero latent
     np.testing.assert_allclose(info["distances"][17], g["zero_row_distances"], atol=1e-7)      # all 1.0
     assert W[17].nnz == 10 and np.allclose(W[17].data, 1.0)

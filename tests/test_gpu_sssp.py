@@ -431,7 +431,8 @@ def test_large_graph_takes_fixed_point_layout_and_falls_back_to_64_source_batche
 def _set_options(request, **opts):
     from vqvae_amd import _lib
     lib = _lib.load()
-    defaults = {"sssp_sb": -1, "sssp_push": 1, "sssp_delta": 4, "sssp_u32": 1, "sssp_group": 1, "sssp_push_blocks": 64}
+    defaults = {"sssp_sb": -1, "sssp_push": 1, "sssp_delta": 4, "sssp_u32": 1, "sssp_group": 1, "sssp_push_blocks": 64,
+                "sssp_push_persistent": 1}
     for name, value in opts.items():
         _lib.check(lib.geo_set_option(name.encode(), int(value)), "geo_set_option")
         request.addfinalizer(lambda name=name: lib.geo_set_option(name.encode(), defaults[name]))
@@ -467,7 +468,7 @@ def test_long_geodesics_with_wide_weights_take_the_near_far_push_solve(request):
     src = np.concatenate([src, src[[3, 40, 69]]])
     Do, Po = osp.dijkstra_multi_source(W, src, return_predecessors=True)
     D, P = dijkstra_multi_source(W, src, return_predecessors=True)
-    assert _lib.load().geo_sssp_last_profile(None, None) == 4016
+    assert _lib.load().geo_sssp_last_profile(None, None) == 5016       # ... all sweeps in one launch (XCD teams)
     np.testing.assert_array_equal(D, Do)
     np.testing.assert_array_equal((P < 0), (Po < 0))
     rows, cols = np.nonzero(np.isfinite(Do) & (P >= 0))
@@ -479,12 +480,13 @@ def test_long_geodesics_with_wide_weights_take_the_near_far_push_solve(request):
     np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
 
 
-@pytest.mark.parametrize("delta", [1, 4, 1000000])
-def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, request):
+@pytest.mark.parametrize("delta,persistent", [(1, 1), (4, 1), (1000000, 1), (4, 0), (1, 0)])
+def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persistent, request):
     """`sssp_push=2` + 16-source batches send EVERY call with more than 16 sources through the push solve, whatever the
     graph: Gaussian clouds and swiss rolls, one binade of weights or eleven, unweighted, a disconnected graph (inf
     columns, idle batches), duplicate and padded sources, for a narrow bucket (delta = 1 mean weight: many release
-    sweeps), the default and an infinite one (plain push label correcting).  All equal the oracle bit for bit."""
+    sweeps), the default and an infinite one (plain push label correcting); with all sweeps in ONE launch (a team of
+    workgroups per XCD, layout 5016) and with one launch per sweep (4016).  All equal the oracle bit for bit."""
     import torch
     from oracle import knn as okn
     from oracle import sssp as osp
@@ -492,7 +494,8 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, request)
     from vqvae_amd import _lib
     from vqvae_amd._device import DeviceCSR, device
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
-    _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta)
+    _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta, sssp_push_persistent=persistent)
+    layout = 5016 if persistent else 4016
     rs = np.random.RandomState(77)
     cases = [(3000, 6, 17, False, 0), (9000, 4, 33, True, 1), (15000, 10, 70, False, 2), (12000, 6, 130, True, 2),
              (6000, 4, 40, True, 0), (3000, 4, 130, True, 3)]
@@ -510,7 +513,7 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, request)
         src[-1] = src[0]                                                # a duplicate source
         Do = osp.dijkstra_multi_source(W, src)
         np.testing.assert_array_equal(dijkstra_multi_source(W, src), Do, err_msg=str((case, n, k, S, roll, mode)))
-        assert _lib.load().geo_sssp_last_profile(None, None) == 4016
+        assert _lib.load().geo_sssp_last_profile(None, None) == layout
         G = DeviceCSR.from_scipy(W, device())
         _, _, dmin, arg, _ = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
         np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))

@@ -31,6 +31,10 @@ _SIGNATURES = {
     "geo_sssp_multi": (ctypes.c_int, [c_p, c_p, c_p, i32, i64, c_p, i32, c_p, c_p, c_p, c_p, c_p, sz, c_p, c_p]),
     "geo_sssp_last_profile": (ctypes.c_int, [c_p, c_p]),
     "geo_sssp_plan": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+    "geo_prior_attention_fwd": (ctypes.c_int, [c_p, c_p, ctypes.c_float, i32, i32, i32, i32, c_p, c_p, c_p]),
+    "geo_prior_attention_bwd": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_float, c_p, i32, i32, i32, i32, c_p, c_p]),
+    "geo_prior_adamw": (ctypes.c_int, [c_p, c_p, c_p, c_p, i64, c_p, c_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, c_p]),
     "geo_sssp_single_update": (ctypes.c_int, [c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i32, c_p, sz, c_p, c_p]),
     "geo_kpp_workspace_bytes": (sz, [i32]),
     "geo_cluster_costs": (ctypes.c_int, [c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p]),

@@ -20,6 +20,7 @@ const OptionName kOptionNames[] = {
     {"sssp_push", "GEO_SSSP_PUSH", &Options::sssp_push},
     {"sssp_delta", "GEO_SSSP_DELTA", &Options::sssp_delta},
     {"sssp_push_blocks", "GEO_SSSP_PUSH_BLOCKS", &Options::sssp_push_blocks},
+    {"sssp_push_persistent", "GEO_SSSP_PUSH_PERSISTENT", &Options::sssp_push_persistent},
     {"knn_filter", "GEO_KNN_FILTER", &Options::knn_filter},
     {"kpp_grid", "GEO_KPP_GRID", &Options::kpp_grid},
     {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},

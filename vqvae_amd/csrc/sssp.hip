@@ -521,13 +521,19 @@ __global__ __launch_bounds__(256) void sweep_chunk32u_kernel(const int32_t *__re
 // State per batch b (16 sources, dist[b][node][16] as in the chunked solve), all in the caller's workspace:
 //   near[parity][b][.]  rows to push this sweep / next sweep, near_cnt ring of 3 (consume, build, clear)
 //   far[ring of 3][b][.] the far pile; a release sweep (near empty) compacts it into the next ring slot
-//   near_stamp[b][v] = sweep for which v is already queued, far_flag[b][v] = 1 while v sits in the pile (dedupe)
+//   near_bits[parity][b] one bit per row: already queued for the sweep of that parity; far_bits[b]: sits in the pile.
+//     Bitmaps, not one word per row: 7.5 KB per batch stay in the L2, where a returning atomic costs a few hundred ns -- the
+//     same dedupe through one int per (batch, row) was a random access into 7.7 MB per enqueue and half of the solve's time.
 //   theta[parity][b], far_slot[parity][b]: written by the batch's first block for the next sweep.
 // Every block of a batch derives the same decision (push / release / idle) from the counts the previous launch left.
 struct PushState {
-    int32_t *near_lists, *near_cnt, *far_lists, *far_cnt, *far_slot, *near_stamp, *far_flag, *active;
+    int32_t *near_lists, *near_cnt, *far_lists, *far_cnt, *far_slot, *active;
+    uint32_t *near_bits, *far_bits;                          // [2][nb][words], [nb][words]
+    int32_t words;
     double *theta;
+    const int32_t *chunk_off, *chunk_node, *chunk_start;     // 16-entry chunks of the CSR rows (the near list holds chunk ids)
     int32_t cs;          // row stride of the per-batch rings (multiple of 32 ints: a 128-byte line of their own)
+    int32_t cap;         // entries per near list (= chunks of the graph)
 };
 
 __device__ __forceinline__ double slot_min16(double x) {
@@ -536,49 +542,36 @@ __device__ __forceinline__ double slot_min16(double x) {
     return x;
 }
 
-// queue the rows named by the slot's lanes (lane = one edge's far end `v`, `want` = it was lowered): dedupe through the
-// stamp / flag word (lanes in parallel), then ONE counter atomic per list and slot, entries written at base + rank
-__device__ __forceinline__ void push_enqueue16(const PushState &st, int32_t b, int32_t n, int32_t v, bool want, bool near,
-                                               int32_t stamp, int32_t *near_out, int32_t c_out, int32_t *far_now,
-                                               int32_t f_now, int lane) {
-    bool first = false;
-    if (want) {
-        if (near) first = atomicExch(&st.near_stamp[(size_t)b * n + v], stamp) != stamp;
-        else first = atomicExch(&st.far_flag[(size_t)b * n + v], 1) == 0;
+// Atomics of the push solve (relaxed, device scope; on gfx950 an atomic RMW is the same instruction at workgroup and agent
+// scope, so pinning a batch to one XCD buys L2 locality for its rows, stamps and counters, not a cheaper instruction).
+template <typename T>
+__device__ __forceinline__ T push_atomic_min(T *p, T v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t push_atomic_exch(int32_t *p, int32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t push_atomic_add(int32_t *p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exclusive prefix sum over the 16 lanes of a slot (DPP-free: 4 shuffle steps), and the slot's total
+__device__ __forceinline__ int slot_scan16(int x, int lane16, int *total) {
+    int incl = x;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const int y = __shfl_up(incl, off, 16);
+        if (lane16 >= off) incl += y;
     }
-    const int sh = (lane >> 4) * 16;
-    const unsigned nm = (unsigned)((__ballot(first && near) >> sh) & 0xffffull);
-    const unsigned fm = (unsigned)((__ballot(first && !near) >> sh) & 0xffffull);
-    const unsigned below = (1u << (lane & 15)) - 1u;
-    if (nm) {
-        const int leader = __ffs((int)nm) - 1;
-        int32_t base = 0;
-        if ((lane & 15) == leader) base = atomicAdd(&st.near_cnt[c_out * st.cs + b], __popc(nm));
-        base = __shfl(base, leader, 16);
-        if (first && near) near_out[base + __popc(nm & below)] = v;
-    }
-    if (fm) {
-        const int leader = __ffs((int)fm) - 1;
-        int32_t base = 0;
-        if ((lane & 15) == leader) base = atomicAdd(&st.far_cnt[f_now * st.cs + b], __popc(fm));
-        base = __shfl(base, leader, 16);
-        if (first && !near) far_now[base + __popc(fm & below)] = v;
-    }
+    *total = __shfl(incl, 15, 16);
+    return incl - x;
 }
 
-// Block -> batch: blocks are dealt round-robin over the 8 XCDs, so  batch = xcd + 8 * (..)  keeps ALL blocks of a batch on
-// one XCD: its distance rows, stamps and counters stay in that XCD's L2, where the atomics execute.
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                        const float *__restrict__ weights, int32_t n, int32_t nb,
-                                                        int32_t blocks_per_batch, double *dist, PushState st, double delta,
-                                                        int32_t sweep) {
-    const int groups8 = (nb + 7) >> 3;
-    const int q = blockIdx.x >> 3;
-    const int b = (blockIdx.x & 7) + 8 * (q % groups8), xb = q / groups8;
+// One sweep of ONE batch by the blocks assigned to it (xb = this block's position among them, blocks_per_batch of them).
+// Work item of a push sweep = one 16-entry CHUNK of a changed row (hub rows of several hundred entries spread over slots
+// instead of serialising one), named by its chunk id in the near list.  Returns false once the batch has nothing left.
+// SLOTS = 16-lane slots per block (blockDim.x / 16).  Every block of the batch derives the same decision (push / release /
+// idle) from the counts the previous sweep left.
+template <bool WEIGHTED, int SLOTS>
+__device__ __forceinline__ bool push_batch_sweep(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                 const float *__restrict__ weights, int32_t n, int32_t nb, int32_t b, int32_t xb,
+                                                 int32_t blocks_per_batch, double *dist, const PushState &st, double delta,
+                                                 int32_t sweep) {
     const int par = sweep & 1, c_in = sweep % 3, c_out = (sweep + 1) % 3, c_clr = (sweep + 2) % 3;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.active[c_out] = 0;
-    if (b >= nb) return;
     const int32_t nn = st.near_cnt[c_in * st.cs + b];
     const int32_t f_now = st.far_slot[par * st.cs + b];
     const int32_t nf = st.far_cnt[f_now * st.cs + b];
@@ -591,71 +584,72 @@ __global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restri
         st.far_slot[(par ^ 1) * st.cs + b] = f_out;
         st.near_cnt[c_clr * st.cs + b] = 0;
         if (release) st.far_cnt[((f_now + 2) % 3) * st.cs + b] = 0;
-        if (nn > 0 || nf > 0) st.active[c_in] = 1;
     }
-    if (nn == 0 && nf == 0) return;                          // this batch has reached its fixed point
+    if (nn == 0 && nf == 0) return false;                    // this batch has reached its fixed point
 
     const int lane = threadIdx.x & 63;
     const unsigned s = lane & 15;
+    const int sh = (lane >> 4) * 16;
     const int slot_in_block = threadIdx.x >> 4;
-    const int32_t stride = blocks_per_batch * 16;
+    const int32_t stride = blocks_per_batch * SLOTS;
     double *D = dist + (size_t)b * n * 16;
-    unsigned long long *Dbits = reinterpret_cast<unsigned long long *>(D);
-    const int32_t *near_in = st.near_lists + ((size_t)par * nb + b) * n;
-    int32_t *near_out = st.near_lists + ((size_t)(par ^ 1) * nb + b) * n;
+    const int32_t *near_in = st.near_lists + ((size_t)par * nb + b) * st.cap;
+    int32_t *near_out = st.near_lists + ((size_t)(par ^ 1) * nb + b) * st.cap;
     int32_t *far_now = st.far_lists + ((size_t)f_now * nb + b) * n;
-    const int32_t stamp = sweep + 1;
+    uint32_t *qbits = st.near_bits + ((size_t)(par ^ 1) * nb + b) * st.words;      // dedupe of the list being built
+    uint32_t *fbits = st.far_bits + (size_t)b * st.words;
+    {   // the other parity's bitmap served the list this sweep consumes: clear it for the sweep after next
+        uint32_t *old = st.near_bits + ((size_t)par * nb + b) * st.words;
+        for (int32_t i = xb * SLOTS * 16 + threadIdx.x; i < st.words; i += blocks_per_batch * SLOTS * 16) old[i] = 0u;
+    }
+    int32_t *ncount = &st.near_cnt[c_out * st.cs + b];
 
-    if (release) {
-        // theta advanced: rows of the pile that are now near move to the near list, the others to the next ring slot.
-        // Lane j of a slot takes entry i + j of the pile; the row's 16 distances are read by the whole slot in turn.
-        int32_t *far_out = st.far_lists + ((size_t)f_out * nb + b) * n;
-        for (int32_t i0 = (xb * 16 + slot_in_block) * 16; i0 < nf; i0 += stride * 16) {
+    // List appends are reserved per BLOCK and round: every slot posts how many near-list entries (chunks) and far-pile
+    // entries (rows) it has, one thread adds the block's totals to the batch's counters, the slots write at their
+    // offsets.  (One returning atomic per slot on a counter shared by the ~1000 slots of a batch serialises at the L2:
+    // measured ~40 us per round, whatever the amount of work.)
+    __shared__ int32_t sh_cnt[2][2][SLOTS];                    // [round parity][near, far][slot]
+    __shared__ int32_t sh_base[2][2];
+    const int32_t n_items = release ? (nf + 15) / 16 : nn;     // work items: 16 pile entries / one chunk per slot
+    const int32_t rounds = (n_items + stride - 1) / stride;    // block-uniform
+    int32_t *far_out = st.far_lists + ((size_t)f_out * nb + b) * n;       // release: the next ring slot; push: the current one
+    int32_t *fcount = &st.far_cnt[f_out * st.cs + b];
+    for (int32_t r = 0; r < rounds; ++r) {
+        const int32_t item = r * stride + xb * SLOTS + slot_in_block;
+        const bool active = item < n_items;
+        int32_t v = -1;                                        // the row this lane speaks for
+        bool to_near = false, to_far = false;
+        if (active && release) {
+            // theta advanced: rows of the pile that are now near move to the near list, the others to the next ring slot.
+            // Lane j of a slot takes entry 16 * item + j of the pile; a row's 16 distances are read by the whole slot.
+            const int32_t i0 = item * 16;
             const int32_t mine = i0 + (int32_t)s < nf ? far_now[i0 + s] : -1;
             double key_mine = inf64();
             for (int j = 0; j < 16; ++j) {
-                const int32_t v = __shfl(mine, j, 16);
-                if (v < 0) break;                                                   // slot-uniform
-                const double key = slot_min16(D[(unsigned)v * 16u + s]);
+                const int32_t vj = __shfl(mine, j, 16);
+                if (vj < 0) break;                                                  // slot-uniform
+                const double key = slot_min16(D[(unsigned)vj * 16u + s]);
                 if ((int)s == j) key_mine = key;
             }
-            const bool live = mine >= 0;
-            const bool near = live && key_mine < th_next;
-            if (near) st.far_flag[(size_t)b * n + mine] = 0;
-            // near rows: dedupe through the stamp; kept rows stay flagged and are appended to the next ring slot
-            bool first = false;
-            if (near) first = atomicExch(&st.near_stamp[(size_t)b * n + mine], stamp) != stamp;
-            const int sh = (lane >> 4) * 16;
-            const unsigned nm = (unsigned)((__ballot(first) >> sh) & 0xffffull);
-            const unsigned km = (unsigned)((__ballot(live && !near) >> sh) & 0xffffull);
-            const unsigned below = (1u << s) - 1u;
-            if (nm) {
-                const int leader = __ffs((int)nm) - 1;
-                int32_t base = 0;
-                if ((int)s == leader) base = atomicAdd(&st.near_cnt[c_out * st.cs + b], __popc(nm));
-                base = __shfl(base, leader, 16);
-                if (first) near_out[base + __popc(nm & below)] = mine;
+            v = mine;
+            if (mine >= 0) {
+                if (key_mine < th_next) {
+                    const uint32_t bit = 1u << (mine & 31);
+                    __hip_atomic_fetch_and(&fbits[mine >> 5], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    to_near = (__hip_atomic_fetch_or(&qbits[mine >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u;
+                } else {
+                    to_far = true;                                                  // stays flagged
+                }
             }
-            if (km) {
-                const int leader = __ffs((int)km) - 1;
-                int32_t base = 0;
-                if ((int)s == leader) base = atomicAdd(&st.far_cnt[f_out * st.cs + b], __popc(km));
-                base = __shfl(base, leader, 16);
-                if (live && !near) far_out[base + __popc(km & below)] = mine;
-            }
-        }
-        return;
-    }
-    // push: a 16-lane slot takes one changed row u and relaxes its edges for the batch's 16 sources
-    for (int32_t i = xb * 16 + slot_in_block; i < nn; i += stride) {
-        const int32_t u = near_in[i];
-        const double du = D[(unsigned)u * 16u + s];
-        const double mu = slot_min16(du);                               // smallest distance of this row over the sources
-        const int32_t e0 = indptr[u], e1 = indptr[u + 1];
-        for (int32_t e = e0; e < e1; e += 16) {
-            const int32_t cnt = e1 - e;
+        } else if (active) {
+            // push: the slot takes one chunk (16 entries of a changed row u) and relaxes it for the batch's 16 sources
+            const int32_t c = near_in[item];
+            const int32_t u = st.chunk_node[c], e = st.chunk_start[c];
+            const int32_t cnt = indptr[u + 1] - e;
+            const double du = D[(unsigned)u * 16u + s];
             const int idx = ((int)s < cnt) ? indices[e + s] : u;         // padding: the row itself at +inf (no effect)
             const int wb = ((int)s < cnt) ? (WEIGHTED ? __float_as_int(weights[e + s]) : 0x3f800000) : 0x7f800000;
+            const double mu = slot_min16(du);                           // smallest distance of this row over the sources
             double dv[16];
             unsigned long long old[16];
             unsigned off[16];
@@ -673,26 +667,140 @@ __global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restri
                 const double cand = du + (double)ww[j];
                 old[j] = 0ull;
                 if (cand < dv[j])
-                    old[j] = atomicMin(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(Dbits) + off[j]),
-                                       (unsigned long long)__double_as_longlong(cand));
+                    old[j] = push_atomic_min(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(D) + off[j]),
+                                             (unsigned long long)__double_as_longlong(cand));
             }
-            unsigned movedmask = 0u;                                     // bit j: some source of the slot lowered edge j's far end
+            unsigned movedmask = 0u;                                     // bit j: some source of the slot lowered entry j's far end
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double cand = du + (double)ww[j];
                 const bool better = old[j] > (unsigned long long)__double_as_longlong(cand);
-                if ((__ballot(better) >> ((lane >> 4) * 16)) & 0xffffull) movedmask |= 1u << j;
+                if ((__ballot(better) >> sh) & 0xffffull) movedmask |= 1u << j;
             }
-            if (movedmask)                                               // lane s speaks for edge s of the chunk
-                push_enqueue16(st, b, n, idx, (movedmask >> s) & 1u, mu + (double)__int_as_float(wb) < th, stamp, near_out,
-                               c_out, far_now, f_now, lane);
+            if ((movedmask >> s) & 1u) {                                 // lane s speaks for entry s of the chunk
+                v = idx;
+                const uint32_t bit = 1u << (idx & 31);
+                uint32_t *word = (mu + (double)__int_as_float(wb) < th ? qbits : fbits) + (idx >> 5);
+                const bool first = (__hip_atomic_fetch_or(word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u;
+                if (mu + (double)__int_as_float(wb) < th) to_near = first;
+                else to_far = first;
+            }
         }
+        // ---- reserve list space for the block, then write
+        int cc = 0, c0 = 0;
+        if (to_near) { c0 = st.chunk_off[v]; cc = st.chunk_off[v + 1] - c0; }
+        int near_total;
+        const int near_before = slot_scan16(cc, (int)s, &near_total);
+        const unsigned fm = (unsigned)((__ballot(to_far) >> sh) & 0xffffull);
+        const int pr = r & 1;
+        if (s == 0) { sh_cnt[pr][0][slot_in_block] = near_total; sh_cnt[pr][1][slot_in_block] = __popc(fm); }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k) tot += sh_cnt[pr][threadIdx.x][k];
+            sh_base[pr][threadIdx.x] = tot ? push_atomic_add(threadIdx.x == 0 ? ncount : fcount, tot) : 0;
+        }
+        __syncthreads();
+        int nbase = sh_base[pr][0], fbase = sh_base[pr][1];
+        for (int k = 0; k < slot_in_block; ++k) { nbase += sh_cnt[pr][0][k]; fbase += sh_cnt[pr][1][k]; }
+        for (int t = 0; t < cc; ++t) near_out[nbase + near_before + t] = c0 + t;
+        if (to_far) far_out[fbase + __popc(fm & ((1u << s) - 1u))] = v;
     }
+    return true;
+}
+
+// ---- one launch per sweep.  Block -> batch: blocks are dealt round-robin over the 8 XCDs, so  batch = xcd + 8 * (..)
+// keeps ALL blocks of a batch on one XCD (its rows, stamps and counters stay in that XCD's L2 during the launch).
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                        const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                        int32_t blocks_per_batch, double *dist, PushState st, double delta,
+                                                        int32_t sweep) {
+    const int groups8 = (nb + 7) >> 3;
+    const int q = blockIdx.x >> 3;
+    const int b = (blockIdx.x & 7) + 8 * (q % groups8), xb = q / groups8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.active[(sweep + 1) % 3] = 0;
+    if (b >= nb) return;
+    const bool busy = push_batch_sweep<WEIGHTED, 16>(indptr, indices, weights, n, nb, b, xb, blocks_per_batch, dist, st, delta, sweep);
+    if (busy && xb == 0 && threadIdx.x == 0) st.active[sweep % 3] = 1;
+}
+
+// ---- ALL sweeps in ONE launch: a team of workgroups per XCD ----------------------------------------------------------
+// Kernel boundaries drop the L2 (the XCDs' L2s are not coherent with each other, so every launch starts cold): with one
+// launch per sweep each of the ~9 dependent loads / atomics of a sweep is served by the Infinity Cache, ~45 us per sweep
+// however little work it has (measured; scratch/micro/atom.hip), times several hundred sweeps.  Here the batches of an XCD
+// (batch % 8 == XCD) are solved to the end by the workgroups resident on THAT XCD: they share its L2, where returning
+// atomics take ~370 ns, so a sweep boundary is one team barrier on an L2 counter and the rows of the moving fronts stay
+// cached from sweep to sweep.  Teams of different XCDs never synchronise (batches are independent).
+//   * blockIdx % 8 is ASSUMED to be the XCD (round-robin dispatch); every block checks it against the XCC_ID hardware
+//     register and raises ctl.abort otherwise -- the host then solves the call with one launch per sweep;
+//   * the barrier spins with a bound: a team member that does not arrive (workgroups of the grid not co-resident) also
+//     ends in ctl.abort, never in a hang; every wave reaches the exit.
+//   * team members see each other's plain stores through the shared L2; a sweep starts with an agent-scope acquire
+//     (invalidates the CU's L1).  Stale L1 lines inside a sweep can only hold OLDER (larger) distances, which cost work,
+//     not correctness -- the same argument as for one launch per sweep.
+struct TeamCtl {
+    int32_t *bar;        // 8 counters, 32 ints apart
+    int32_t *abort;      // 0 ok, 1 barrier timeout, 2 block not on its XCD
+    int32_t *sweeps;     // [8] sweeps each XCD's team ran
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xfu;     // HW_REG_XCC_ID (20), bits 3:0
+#else
+    return 0u;
+#endif
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(512) void push_persistent_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                             const float *__restrict__ weights, int32_t n, int32_t nb,
+                                                             double *dist, PushState st, double delta, TeamCtl ctl, int32_t team,
+                                                             int32_t max_sweeps, int32_t spin_limit) {
+    __shared__ int32_t sh_go;
+    const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3;
+    const int groups8 = (nb + 7) >> 3;
+    if (threadIdx.x == 0 && xcc_id() != (unsigned)xcd) __hip_atomic_store(ctl.abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t *bar = ctl.bar + xcd * 32;
+    int32_t sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        bool busy = false;
+        for (int g = 0; g < groups8; ++g) {
+            const int b = xcd + 8 * g;
+            if (b < nb)
+                busy |= push_batch_sweep<WEIGHTED, 32>(indptr, indices, weights, n, nb, b, member, team, dist, st, delta, sweep);
+        }
+        // ---- team barrier: stores of this block are in the L2 (write-through L1, waited for) before it signs in
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t target = (sweep + 1) * team;
+            int32_t go = 1, spins = 0;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (__hip_atomic_load(ctl.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { go = 0; break; }
+                if (++spins > spin_limit) {
+                    __hip_atomic_store(ctl.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    go = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (__hip_atomic_load(ctl.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) go = 0;
+            sh_go = go;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!sh_go || !busy) break;                              // `busy` is the same in every block of the team
+    }
+    if (member == 0 && threadIdx.x == 0) ctl.sweeps[xcd] = sweep + 1;
 }
 
 __global__ __launch_bounds__(256) void push_init_kernel(const int32_t *__restrict__ src_pad, int32_t n, int32_t nb, PushState st,
                                                        double delta) {
-    // one block per batch: near list = the batch's distinct sources, everything else empty
+    // one block per batch: near list = the chunks of the batch's distinct sources, everything else empty
     const int b = blockIdx.x;
     if (threadIdx.x < 3) {
         st.near_cnt[threadIdx.x * st.cs + b] = 0;
@@ -702,12 +810,16 @@ __global__ __launch_bounds__(256) void push_init_kernel(const int32_t *__restric
         st.theta[threadIdx.x * st.cs + b] = delta;
         st.far_slot[threadIdx.x * st.cs + b] = 0;
     }
-    if (b == 0 && threadIdx.x < 3) st.active[threadIdx.x] = 0;
+    if (b == 0 && threadIdx.x < 16) st.active[threadIdx.x] = 0;
     __syncthreads();
     if (threadIdx.x < 16) {
         const int32_t v = src_pad[b * 16 + threadIdx.x];
-        if (v >= 0 && v < n && atomicExch(&st.near_stamp[(size_t)b * n + v], 0x7fffffff) != 0x7fffffff)
-            st.near_lists[(size_t)b * n + atomicAdd(&st.near_cnt[b], 1)] = v;          // parity 0, ring slot 0 = sweep 0
+        // (dedupe of repeated sources through parity-0 bits; sweep 0 clears them again)
+        if (v >= 0 && v < n && (atomicOr(&st.near_bits[(size_t)b * st.words + (v >> 5)], 1u << (v & 31)) & (1u << (v & 31))) == 0u) {
+            const int32_t c0 = st.chunk_off[v], cc = st.chunk_off[v + 1] - c0;
+            const int32_t base = atomicAdd(&st.near_cnt[b], cc);                   // parity 0, ring slot 0 = sweep 0
+            for (int32_t t = 0; t < cc; ++t) st.near_lists[(size_t)b * st.cap + base + t] = c0 + t;
+        }
     }
 }
 
@@ -719,10 +831,11 @@ __global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
-size_t push_bytes(int32_t n, int32_t nb) {
+size_t push_bytes(int32_t n, int64_t nnz, int32_t nb) {
     const size_t cs = ((size_t)nb + 31) / 32 * 32, per = (size_t)nb * n;
-    return geo::align_up(2 * per * 4) + geo::align_up(3 * per * 4) + 2 * geo::align_up(per * 4) + geo::align_up(3 * cs * 4) * 2 +
-           geo::align_up(2 * cs * 4) + geo::align_up(2 * cs * 8) + 512 + 256;
+    const size_t cap = (size_t)n + (size_t)(nnz / 16) + 16;                     // chunks of the graph (upper bound)
+    return geo::align_up(2 * (size_t)nb * cap * 4) + geo::align_up(3 * per * 4) + 2 * geo::align_up(per * 4) +
+           geo::align_up(3 * cs * 4) * 2 + geo::align_up(2 * cs * 4) + geo::align_up(2 * cs * 8) + 512 + 256 + 4096;
 }
 
 __device__ __forceinline__ double units_to_f64(uint32_t u, double unit) { return u == U_INF ? inf64() : (double)u * unit; }
@@ -1011,7 +1124,7 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
            geo::align_up(4 * (((size_t)nb + 31) / 32 * 32) * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) +
-           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024 + push_bytes(n, nb);
+           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024 + push_bytes(n, nnz, nb);
 }
 
 // slots of a solve: whole batches of `sb` sources, and (for the 32-source fixed-point layout of the same buffers) of 32
@@ -1078,6 +1191,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     uint32_t *wunits = nullptr, *wrange = nullptr;           // 32-bit fixed-point weights / their range
     int32_t *chunk_cnt = nullptr, *row_order = nullptr;
     PushState push{};
+    int32_t *team_ctl = nullptr;
     double *wsum = nullptr;
     const geo::Options &opt = geo::options();
     const int act_mode = opt.sssp_act;
@@ -1106,19 +1220,25 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         wrange = ar.take<uint32_t>(4);
         const size_t per = (size_t)nb * n;
         push.cs = cs;
-        push.near_lists = ar.take<int32_t>(2 * per);
+        push.cap = (int32_t)max_chunks;
+        push.chunk_off = coff;
+        push.chunk_node = chunk_node;
+        push.chunk_start = chunk_start;
+        push.near_lists = ar.take<int32_t>(2 * (size_t)nb * max_chunks);
         push.far_lists = ar.take<int32_t>(3 * per);
-        push.near_stamp = ar.take<int32_t>(per);
-        push.far_flag = ar.take<int32_t>(per);
+        push.words = (n + 31) / 32;
+        push.near_bits = ar.take<uint32_t>(2 * (size_t)nb * push.words);
+        push.far_bits = ar.take<uint32_t>((size_t)nb * push.words);
         push.near_cnt = ar.take<int32_t>(3 * (size_t)cs);
         push.far_cnt = ar.take<int32_t>(3 * (size_t)cs);
         push.far_slot = ar.take<int32_t>(2 * (size_t)cs);
         push.theta = ar.take<double>(2 * (size_t)cs);
         push.active = ar.take<int32_t>(64);
+        team_ctl = ar.take<int32_t>(512);
         wsum = ar.take<double>(8);
         GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange && push.near_lists &&
-                        push.far_lists && push.near_stamp && push.far_flag && push.near_cnt && push.far_cnt && push.far_slot &&
-                        push.theta && push.active && wsum,
+                        push.far_lists && push.near_bits && push.far_bits && push.near_cnt && push.far_cnt && push.far_slot &&
+                        push.theta && push.active && team_ctl && wsum,
                     "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
@@ -1328,7 +1448,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                                    argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }
     int32_t total_sweeps = 0;
-    bool pushed = false;
+    bool pushed = false, persistent = false;
     // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
     // sources moved a neighbour, so with 16 scattered sources every row is re-evaluated as each of 16 fronts
     // passes (and their corrections cascade), with 16 neighbouring sources the fronts pass as one.  On graphs
@@ -1362,15 +1482,62 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                 mean_w /= (double)nnz;
             }
             const double delta = (opt.sssp_delta > 0 ? (double)opt.sssp_delta : 4.0) * (mean_w > 0.0 ? mean_w : 1.0);
-            const size_t per = (size_t)nb * n;
-            GEO_HIP_CHECK(hipMemsetAsync(push.near_stamp, 0, per * 4, stream));
-            GEO_HIP_CHECK(hipMemsetAsync(push.far_flag, 0, per * 4, stream));
-            push_init_kernel<<<nb, 256, 0, stream>>>(w.src_pad, n, nb, push, delta);
-            GEO_LAUNCH_CHECK();
+            auto push_reset = [&]() -> int {
+                GEO_HIP_CHECK(hipMemsetAsync(push.near_bits, 0, 2 * (size_t)nb * push.words * 4, stream));
+                GEO_HIP_CHECK(hipMemsetAsync(push.far_bits, 0, (size_t)nb * push.words * 4, stream));
+                push_init_kernel<<<nb, 256, 0, stream>>>(w.src_pad, n, nb, push, delta);
+                GEO_LAUNCH_CHECK();
+                return GEO_OK;
+            };
+            if (int rc = push_reset()) return rc;
+            const int64_t plimit = 64 * (int64_t)n + 64;
+            // ---- all sweeps in one launch, a team of workgroups per XCD (push_persistent_kernel) ----
+            if (opt.sssp_push_persistent != 0) {
+                static int n_cu = 0, fits = -1;
+                if (fits < 0) {
+                    int devid = 0, per_cu = 0;
+                    hipDeviceProp_t prop;
+                    GEO_HIP_CHECK(hipGetDevice(&devid));
+                    GEO_HIP_CHECK(hipGetDeviceProperties(&prop, devid));
+                    n_cu = prop.multiProcessorCount;
+                    GEO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, push_persistent_kernel<true>, 512, 0));
+                    fits = per_cu >= 1 && n_cu >= 8 ? 1 : 0;
+                }
+                if (fits) {
+                    const int team = std::min(32, n_cu / 8);         // one workgroup per CU, 8 XCDs
+                    TeamCtl ctl{team_ctl, team_ctl + 256, team_ctl + 264};
+                    GEO_HIP_CHECK(hipMemsetAsync(team_ctl, 0, 512 * sizeof(int32_t), stream));
+                    GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
+                    const int32_t max_sweeps = (int32_t)std::min<int64_t>(plimit, 1 << 24);
+                    if (weights) push_persistent_kernel<true><<<8 * team, 512, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, push, delta, ctl, team, max_sweeps, 1 << 20);
+                    else push_persistent_kernel<false><<<8 * team, 512, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, push, delta, ctl, team, max_sweeps, 1 << 20);
+                    GEO_LAUNCH_CHECK();
+                    GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
+                    int32_t hctl[16];
+                    GEO_HIP_CHECK(hipMemcpyAsync(hctl, team_ctl + 256, sizeof(hctl), hipMemcpyDeviceToHost, stream));
+                    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+                    int32_t most = 0;
+                    for (int x = 0; x < 8; ++x) most = std::max(most, hctl[8 + x]);
+                    if (opt.sssp_trace) fprintf(stderr, "[sssp-push] persistent teams of %d: abort=%d, sweeps per XCD %d %d %d %d %d %d %d %d\n", team, hctl[0],
+                                                hctl[8], hctl[9], hctl[10], hctl[11], hctl[12], hctl[13], hctl[14], hctl[15]);
+                    if (hctl[0] == 0 && most < max_sweeps) {
+                        float ms = 0.f;
+                        GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+                        g_last_sweep_ms += ms;
+                        total_sweeps += most;
+                        pushed = true;
+                        persistent = true;
+                        break;
+                    }
+                    // a block off its XCD, or a team that did not assemble: start over with one launch per sweep
+                    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
+                    GEO_LAUNCH_CHECK();
+                    if (int rc = push_reset()) return rc;
+                }
+            }
             const int bpb = opt.sssp_push_blocks > 0 ? opt.sssp_push_blocks : 64;
             const unsigned pgrid = (unsigned)(((nb + 7) / 8) * 8) * (unsigned)bpb;        // batch <-> XCD: see push_sweep_kernel
             int32_t sweeps = 0, hact = 1;
-            const int64_t plimit = 64 * (int64_t)n + 64;
             int group_len = 8;
             while (hact) {
                 int last = 0;
@@ -1488,8 +1655,8 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     }
     const int32_t sweeps = total_sweeps;
     if (sweeps_out) *sweeps_out = sweeps;
-    g_last_sweep_launches = sweeps;
-    g_last_layout = sb + (chunked ? 1000 : 0) + (pushed ? 3000 : 0);          // 4016 = near-far push solve
+    g_last_sweep_launches = persistent ? 1 : sweeps;                          // the persistent solve is ONE launch
+    g_last_layout = sb + (chunked ? 1000 : 0) + (pushed ? 3000 : 0) + (persistent ? 1000 : 0);   // 4016 near-far push solve, 5016 in one launch
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {

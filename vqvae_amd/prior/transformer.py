@@ -24,6 +24,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import native
+
 
 class Slot(NamedTuple):
     """One named tensor of the arena: where it lives and how a fresh model fills it."""
@@ -74,6 +76,8 @@ class Transformer(nn.Module):
         # where that buffer is zero; the buffers are carried (and honoured, should a checkpoint hold other values)
         self.register_buffer("mask_bias", torch.tril(torch.ones(max_seq_len, max_seq_len)).repeat(n_layers, 1, 1),
                              persistent=False)
+        self._standard_mask = True      # mask buffers are the lower triangle (checked whenever a checkpoint is loaded)
+        self.fused_attention = True     # GPU: csrc/prior.hip's attention kernels when they cover the shape
         self._fresh_weights()
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -142,6 +146,8 @@ class Transformer(nn.Module):
             for k, t in list(views.items()) + list(masks.items()):
                 if k in state_dict:
                     t.copy_(state_dict[k])
+            T = self.max_seq_len
+            self._standard_mask = bool(((self.mask_bias == 0) == (torch.tril(torch.ones(T, T, device=self.mask_bias.device)) == 0)).all())
         return nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # ------------------------------------------------------------------------------------------ forward
@@ -156,14 +162,18 @@ class Transformer(nn.Module):
             x = x + F.embedding(y, p["class_emb.weight"])[:, None, :]
         scale = 1.0 / math.sqrt(C // H)
         hidden = self.mask_bias[:, :T, :T] == 0                                   # (layers, T, T): True = not attended
+        fused = (self.fused_attention and idx.is_cuda and self._standard_mask and native.attention_kernel_covers(T, C // H))
         for i in range(self.n_layers):
             b = f"blocks.{i}."
             h = F.layer_norm(x, (C,), p[b + "ln1.weight"], p[b + "ln1.bias"])
-            qkv = F.linear(h, p[b + "attn.c_attn.weight"], p[b + "attn.c_attn.bias"]).view(B, T, 3, H, C // H)
-            q, k, v = qkv.permute(2, 0, 3, 1, 4)                                  # each (B, H, T, C/H)
-            w = (q @ k.transpose(-2, -1) * scale).masked_fill(hidden[i], float("-inf"))
-            w = F.dropout(torch.softmax(w, dim=-1), drop, self.training)
-            a = (w @ v).transpose(1, 2).reshape(B, T, C)
+            qkv = F.linear(h, p[b + "attn.c_attn.weight"], p[b + "attn.c_attn.bias"])
+            if fused:
+                a = native.causal_attention(qkv, H, drop)                         # one kernel (and one for its backward)
+            else:
+                q, k, v = qkv.view(B, T, 3, H, C // H).permute(2, 0, 3, 1, 4)     # each (B, H, T, C/H)
+                w = (q @ k.transpose(-2, -1) * scale).masked_fill(hidden[i], float("-inf"))
+                w = F.dropout(torch.softmax(w, dim=-1), drop, self.training)
+                a = (w @ v).transpose(1, 2).reshape(B, T, C)
             x = x + F.dropout(F.linear(a, p[b + "attn.c_proj.weight"], p[b + "attn.c_proj.bias"]), drop, self.training)
             h = F.layer_norm(x, (C,), p[b + "ln2.weight"], p[b + "ln2.bias"])
             h = F.linear(F.gelu(F.linear(h, p[b + "mlp.0.weight"], p[b + "mlp.0.bias"])), p[b + "mlp.2.weight"], p[b + "mlp.2.bias"])

@@ -40,7 +40,8 @@ def main(config_path: str):
         torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if use_gpu:
+        # RCCL ("nccl") needs a GPU per rank; GEO_PRIOR_BACKEND=gloo lets ranks share one (rehearsals, 1-GPU boxes)
+        if use_gpu and os.environ.get("GEO_PRIOR_BACKEND", "nccl") == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
@@ -64,6 +65,7 @@ def main(config_path: str):
         ckpt_dir.mkdir(parents=True, exist_ok=True)
     history = train_prior(model, train_loader, val_loader, epochs=int(train_cfg["epochs"]), lr=float(train_cfg["lr"]),
                           weight_decay=float(train_cfg["weight_decay"]), device=device, ckpt_dir=ckpt_dir)
+    history["arena_sum"] = float(model.arena.detach().double().sum())       # one number to compare ranks by
     if dist.is_initialized():
         dist.destroy_process_group()
     return history
