@@ -1,7 +1,7 @@
 """BASELINE config 5 as a pipeline on the MI355X: geodesic codebook at the CIFAR-10 shape (50 000 images x 4x4 cells =
 800 000 latents of dimension 32, 32-px 3-channel decoder with train-mode BatchNorm, k=20, K=512) through the drop-in CLI
 -> codes.npy -> CodesDataset -> one epoch of the data-parallel prior training CLI on 2 ranks (the reference's
-configs/cifar10/spatial/geodesic/transformer.yaml values: 4 layers, 256 dims, 4 heads, 512 tokens, dropout 0.1, batch 256).
+configs/cifar10/spatial/geodesic/transformer.yaml values: 4 layers, 256 dims, 4 heads, 512 tokens, dropout 0.1; batch 1024).
 No oracle exists at this size (the reference's CPU path would take hours): checked are the artefact contract of
 src/scripts/build_codebook.py:74-103, invariants of the codes, oracle parity on sampled rows / chunks / draws, that the two
 ranks end with identical weights, and that the prior learns the code statistics (loss below the uniform bound)."""
@@ -74,7 +74,9 @@ def test_c5_codebook_cli_then_two_rank_prior_epoch(tmp_path):
     ds = CodesDataset(os.path.join(out, "codes.npy"), os.path.join(tmp, "y.pt"))
     assert len(ds) == N_IMG and ds.seq_len == 16
     cfg = {"system": {"seed": 42, "device": "auto"},
-           "data": {"codes_path": os.path.join(out, "codes.npy"), "labels_path": os.path.join(tmp, "y.pt"), "batch_size": 256,
+           # (the reference's yaml says batch 256; 1024 keeps one epoch at 49 all-reduces: on a 1-GPU box the two ranks share
+           #  the GPU and reduce 13 MB through gloo on the host's CPUs, which a busy pod makes slow)
+           "data": {"codes_path": os.path.join(out, "codes.npy"), "labels_path": os.path.join(tmp, "y.pt"), "batch_size": 1024,
                     "num_workers": 0, "vanilla_vae": False},
            "training": {"epochs": 1, "lr": 3e-4, "weight_decay": 0.01},
            "out": {"dir": os.path.join(tmp, "prior")},
@@ -98,9 +100,9 @@ def test_c5_codebook_cli_then_two_rank_prior_epoch(tmp_path):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
     runs = [json.load(open(os.path.join(tmp, f"c5_rank{r}.json"))) for r in range(world)]
-    steps = (N_IMG + 255) // 256
+    steps = (N_IMG + 1023) // 1024
     assert len(runs[0]["train_loss"]) == steps and runs[0]["train_loss"] == runs[1]["train_loss"]     # lock-step, same losses
     assert runs[0]["arena_sum"] == runs[1]["arena_sum"]                        # identical weights on both ranks
-    first, last = np.mean(runs[0]["train_loss"][:5]), np.mean(runs[0]["train_loss"][-20:])
+    first, last = np.mean(runs[0]["train_loss"][:3]), np.mean(runs[0]["train_loss"][-10:])
     assert abs(first - np.log(K)) < 0.25 and last < np.log(K) - 0.02 and runs[0]["val_loss"][0] < np.log(K)
     assert "token_emb.weight" in runs[0]["keys"] and "blocks.3.attn.bias" in runs[0]["keys"]            # reference state dict
