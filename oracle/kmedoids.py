@@ -171,3 +171,45 @@ def voronoi_iteration(W, medoids0, max_iter: int = 10, power: int = 2, D: np.nda
         history.append(quantization_error_from(D[med][assign, np.arange(D.shape[0])]))
     return med, assign, history[-1], history
 
+
+
+# ---- extension: PAM swap (no reference implementation: parity against this restatement only) ---------------------------
+def total_cost(D: np.ndarray, medoids, power: int = 2) -> float:
+    """sum_j (distance of j to its nearest medoid)^power, fp64."""
+    return float((D[np.asarray(medoids)].astype(np.float64).min(axis=0) ** power).sum())
+
+
+def pam_swap_pass(D: np.ndarray, medoids, power: int = 2):
+    """The best single swap (medoid position i -> node x) BY DEFINITION: every (i, x) pair is tried and the total cost
+    recomputed.  Returns (delta, i, x) with the most negative delta; ties: lowest x, then lowest i.  O(K n * K n): small
+    inputs only."""
+    med = np.asarray(medoids, dtype=np.int64)
+    n, K = D.shape[0], len(med)
+    base = total_cost(D, med, power)
+    best = (np.inf, 0, 0)
+    is_med = np.zeros(n, bool)
+    is_med[med] = True
+    Dp = D.astype(np.float64) ** power
+    for x in range(n):
+        if is_med[x]:
+            continue
+        for i in range(K):
+            trial = med.copy()
+            trial[i] = x
+            delta = float(Dp[trial].min(axis=0).sum()) - base
+            if delta < best[0]:
+                best = (delta, i, x)
+    return best
+
+
+def pam(D: np.ndarray, medoids0, power: int = 2, max_swaps: int = 100, rel_tol: float = 1e-12):
+    """Classic PAM: apply the best swap while it lowers the total cost.  Returns (medoids, assign, cost history)."""
+    med = np.asarray(medoids0, dtype=np.int64).copy()
+    history = [total_cost(D, med, power)]
+    for _ in range(max_swaps):
+        delta, i, x = pam_swap_pass(D, med, power)
+        if not delta < -rel_tol * history[-1]:
+            break
+        med[i] = x
+        history.append(total_cost(D, med, power))
+    return med, np.argmin(D[med], axis=0), history

@@ -16,7 +16,11 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
     python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- \
     python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
-for w in c3 swiss c4; do
-  timeout -k 10 200 python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err || exit 1
+for w in c3 swiss c4 real c5cb; do
+  timeout -k 10 300 python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err || exit 1
 done
+timeout -k 10 200 python3 $GRAFT_REPO_ROOT/bench.py --workload c5prior --steps 100 --warmup 10 > $OUT/bench_c5prior.json 2> $OUT/bench_c5prior.err || exit 1
+# the long-geodesics solve alone under the kernel trace (per-launch durations of the push sweeps)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_swiss -o t -- \
+    python3 $GRAFT_REPO_ROOT/scratch/exp_solve_jvp.py swiss 2 > $OUT/swiss_solve.log 2> $OUT/trace_swiss.err || exit 1
 echo collected into $OUT

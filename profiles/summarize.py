@@ -17,9 +17,15 @@ def last_json(path):
 
 shutil.copy(glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)[0], f"{dst}/{tag}_c2_kernel_stats.csv")
 for name, out in (("bench.json", "c2_bench"), ("bench_under_rocprof.json", "c2_bench_under_rocprof"),
-                  ("bench_c3.json", "c3_bench"), ("bench_swiss.json", "swiss_bench")):
-    with open(f"{dst}/{tag}_{out}.json", "w") as f:
-        json.dump(last_json(os.path.join(src, name)), f, indent=1)
+                  ("bench_c3.json", "c3_bench"), ("bench_swiss.json", "swiss_bench"), ("bench_c4.json", "c4_bench"),
+                  ("bench_real.json", "real_bench"), ("bench_c5cb.json", "c5cb_bench"), ("bench_c5prior.json", "c5prior_bench")):
+    if os.path.exists(os.path.join(src, name)):
+        with open(f"{dst}/{tag}_{out}.json", "w") as f:
+            json.dump(last_json(os.path.join(src, name)), f, indent=1)
+sw = glob.glob(src + "/trace_swiss/**/*kernel_stats.csv", recursive=True)
+if sw:
+    shutil.copy(sw[0], f"{dst}/{tag}_swiss_solve_kernel_stats.csv")
+    shutil.copy(os.path.join(src, "swiss_solve.log"), f"{dst}/{tag}_swiss_solve.log")
 
 
 def pmc_summary(sub, counter):

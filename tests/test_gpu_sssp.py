@@ -495,7 +495,9 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persiste
     from vqvae_amd._device import DeviceCSR, device
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
     _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta, sssp_push_persistent=persistent)
-    layout = 5016 if persistent else 4016
+    # persistent: 5016 when the XCD teams ran; 4016 when the kernel declined (a block found itself on another XCD than
+    # blockIdx % 8, or a team did not assemble) and the call was answered by one launch per sweep -- both are valid
+    layouts = (5016, 4016) if persistent else (4016,)
     rs = np.random.RandomState(77)
     cases = [(3000, 6, 17, False, 0), (9000, 4, 33, True, 1), (15000, 10, 70, False, 2), (12000, 6, 130, True, 2),
              (6000, 4, 40, True, 0), (3000, 4, 130, True, 3)]
@@ -513,7 +515,7 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persiste
         src[-1] = src[0]                                                # a duplicate source
         Do = osp.dijkstra_multi_source(W, src)
         np.testing.assert_array_equal(dijkstra_multi_source(W, src), Do, err_msg=str((case, n, k, S, roll, mode)))
-        assert _lib.load().geo_sssp_last_profile(None, None) == layout
+        assert _lib.load().geo_sssp_last_profile(None, None) in layouts
         G = DeviceCSR.from_scipy(W, device())
         _, _, dmin, arg, _ = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
         np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))

@@ -91,7 +91,73 @@ __global__ __launch_bounds__(256) void attach_argmin_kernel(const float *__restr
     }
 }
 
+// PAM's SWAP evaluation in the FastPAM1 form: for a candidate x (a row of D) the change of the total cost when medoid i is
+// replaced by x is
+//   dTD(i, x) = sum_j min(c(x,j) - c1(j), 0)  +  sum_{j: nearest(j) = i} [ min(c(x,j), c2(j)) - c1(j) - min(c(x,j) - c1(j), 0) ]
+// with c = D^power, c1 / c2 = cost to the nearest / second-nearest medoid -- all K medoids from ONE pass over row x.
+// One workgroup per candidate; a wave takes whole clusters (members = order[offsets[i] .. offsets[i+1]), ascending node
+// index; c1 / c2 are given in that member order, so they stream), lane-strided fp64 sums + xor butterfly = a fixed summation
+// tree; the cluster terms are then combined in cluster order by thread 0.  Output per candidate: its best medoid to replace
+// (first index on ties) and the change.  The matrix is read exactly once per pass: N^2 x 4 bytes, HBM-bound.
+__global__ __launch_bounds__(256) void pam_swap_kernel(const float *__restrict__ D, int64_t ld, const int32_t *__restrict__ order,
+                                                      const int32_t *__restrict__ offsets, const double *__restrict__ c1m,
+                                                      const double *__restrict__ c2m, const uint8_t *__restrict__ is_medoid,
+                                                      int32_t n, int32_t K, int32_t power, double *__restrict__ best_delta,
+                                                      int32_t *__restrict__ best_medoid) {
+    extern __shared__ double sh[];                             // A[K] (shared term per cluster), B[K] (own-cluster term)
+    double *A = sh, *B = sh + K;
+    const int64_t x = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (is_medoid[x]) {                                        // (block-uniform) a medoid is no candidate
+        if (threadIdx.x == 0) { best_delta[x] = __longlong_as_double(0x7ff0000000000000LL); best_medoid[x] = 0; }
+        return;
+    }
+    const float *row = D + x * ld;
+    for (int32_t i = wave; i < K; i += 4) {
+        const int32_t m0 = offsets[i], m1 = offsets[i + 1];
+        double a = 0.0, b = 0.0;
+        for (int32_t m = m0 + lane; m < m1; m += 64) {
+            const double d = (double)row[order[m]];
+            const double c = power == 2 ? d * d : d;
+            const double c1 = c1m[m], c2 = c2m[m];
+            const double shared = fmin(c - c1, 0.0);
+            a += shared;
+            b += fmin(c, c2) - c1 - shared;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if (lane == 0) { A[i] = a; B[i] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double all = 0.0;
+        for (int32_t i = 0; i < K; ++i) all += A[i];           // cluster order
+        double best = __longlong_as_double(0x7ff0000000000000LL);
+        int32_t arg = 0;
+        for (int32_t i = 0; i < K; ++i) {
+            const double dtd = all + B[i];
+            if (dtd < best) { best = dtd; arg = i; }           // strict: the first medoid wins ties
+        }
+        best_delta[x] = best;
+        best_medoid[x] = arg;
+    }
+}
+
 }  // namespace
+
+extern "C" int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *order, const int32_t *offsets, const double *c1_members,
+                                   const double *c2_members, const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power,
+                                   double *best_delta_out, int32_t *best_medoid_out, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(D && order && offsets && c1_members && c2_members && is_medoid && best_delta_out && best_medoid_out,
+                "geo_pam_swap_deltas: null pointer");
+    GEO_REQUIRE(n > 0 && K > 0 && K <= 4096 && ld >= n && (power == 1 || power == 2), "geo_pam_swap_deltas: bad n=%d K=%d ld=%lld power=%d",
+                n, K, (long long)ld, power);
+    pam_swap_kernel<<<(unsigned)n, 256, 2 * (size_t)K * sizeof(double), stream>>>(D, ld, order, offsets, c1_members, c2_members, is_medoid,
+                                                                                n, K, power, best_delta_out, best_medoid_out);
+    GEO_LAUNCH_CHECK();
+    return GEO_OK;
+}
 
 extern "C" int geo_attach_argmin(const float *Dt, int64_t ld, int32_t K, const int32_t *nbr, const float *len, int32_t k,
                                  int64_t n_new, float *dist_out, int32_t *arg_out, void *stream_) {

@@ -408,3 +408,66 @@ def fit_kmedoids_voronoi(W, K: int = 512, init: str = "kpp", seed: int = 42, max
     print(f"[kmedoids] Voronoi iterations: {len(history) - 1}, qe {history[0]:.3f} -> {history[-1]:.3f}")
     return medoids, assign_h, history[-1], history
 
+
+
+# ---- extension: PAM swap over the resident all-pairs matrix ---------------------------------------------------------------
+def pam_swap_pass_device(D: torch.Tensor, medoids: torch.Tensor, power: int = 2):
+    """PAM's SWAP evaluation for ALL (medoid, candidate) pairs in one pass over the resident matrix (csrc/medoid.hip:
+    pam_swap_kernel, FastPAM1 form).  Returns (delta, i, x, total): the swap medoids[i] -> x with the most negative change of
+    the total cost sum_j D[nearest(j)][j]^power (ties: lowest x, then first medoid), and the current total cost."""
+    lib = _lib.load()
+    dev = D.device
+    n, K = int(D.shape[0]), int(medoids.numel())
+    med = medoids.to(torch.int64)
+    dmin, near = assign_from_rows_device(D, medoids)                 # nearest medoid, first on ties
+    near = near.to(torch.int64)
+    c1 = dmin.double() ** power
+    if K > 1:
+        rows = D[med].double() ** power                              # K x n
+        rows.scatter_(0, near[None, :], float("inf"))
+        c2 = rows.min(dim=0).values
+        del rows
+    else:
+        c2 = torch.full_like(c1, float("inf"))
+    order = torch.argsort(near, stable=True)
+    offsets = torch.zeros(K + 1, dtype=torch.int32, device=dev)
+    offsets[1:] = torch.cumsum(torch.bincount(near, minlength=K), 0).to(torch.int32)
+    is_med = torch.zeros(n, dtype=torch.uint8, device=dev)
+    is_med[med] = 1
+    c1m, c2m, order32 = c1[order].contiguous(), c2[order].contiguous(), order.to(torch.int32).contiguous()
+    best = torch.empty(n, dtype=torch.float64, device=dev)
+    which = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(order32), ptr(offsets), ptr(c1m), ptr(c2m), ptr(is_med), n, K,
+                                           int(power), ptr(best), ptr(which), stream_ptr()), "geo_pam_swap_deltas")
+    delta = best.min()
+    x = int(torch.nonzero(best == delta)[0])                         # lowest candidate among equal changes
+    return float(delta), int(which[x]), x, float(c1.sum())
+
+
+def fit_kmedoids_pam(W, K: int = 512, init: str = "kpp", seed: int = 42, max_swaps: int = 50, power: int = 2,
+                     D: Optional[torch.Tensor] = None, rel_tol: float = 1e-12):
+    """fit_kmedoids_optimized followed by PAM swaps: the best (medoid -> non-medoid) exchange is applied while it lowers the
+    total cost (power=2: the reference's quantisation error).  Extension (the reference's k-medoids
+    is seeding + one assignment, kmeans_optimized.py:141-183).  Every swap evaluation reads the resident N x N matrix once.
+    Returns (medoids, assign, qe, history of total costs)."""
+    from .geo_shortest_paths import all_pairs_geodesic_device
+    G = _to_device_graph(W)
+    dev = G.indptr.device
+    medoids0, _, _ = fit_kmedoids_optimized(W, K=K, init=init, seed=seed)
+    if D is None:
+        D = all_pairs_geodesic_device(G)
+    med = torch.from_numpy(np.asarray(medoids0, dtype=np.int32)).to(dev)
+    history = []
+    for _ in range(max_swaps + 1):
+        delta, i, x, total = pam_swap_pass_device(D, med, power)
+        history.append(total)
+        if len(history) > max_swaps or not delta < -rel_tol * total:
+            break
+        med[i] = x
+    dmin, assign = assign_from_rows_device(D, med)
+    medoids = med.cpu().numpy().astype(int)
+    assign_h = assign.cpu().numpy().astype(int)
+    _print_sizes(assign_h, len(medoids))
+    print(f"[kmedoids] PAM swaps: {len(history) - 1}, total cost {history[0]:.3f} -> {history[-1]:.3f}")
+    return medoids, assign_h, _qe_from(dmin.cpu().numpy()), history
