@@ -292,3 +292,48 @@ def test_held_out_assignment_oracle_against_explicit_graph_extension():
         d = osp.dijkstra_multi_source(Wx, np.asarray(med))[:, n]
         np.testing.assert_allclose(dist[v], d.min(), rtol=1e-6)
         assert d[codes[v]] <= d.min() * (1 + 1e-6)
+
+
+def test_pam_restatement_is_self_consistent():
+    """oracle/kmedoids.py's PAM (extension without a reference): the brute-force swap pass agrees with the FastPAM1 identity
+    the GPU kernel uses, a swap changes the total cost by exactly its delta, and PAM never raises the cost."""
+    from oracle import kmedoids as ok
+    r = np.random.RandomState(0)
+    n, K = 90, 4
+    P = r.rand(n, 3)
+    D = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1)).astype(np.float32)
+    med = r.choice(n, K, replace=False)
+    for power in (1, 2):
+        delta, i, x = ok.pam_swap_pass(D, med, power)
+        Dp = D.astype(np.float64) ** power
+        rows = Dp[med]
+        near, c1 = rows.argmin(0), rows.min(0)
+        r2 = rows.copy()
+        r2[near, np.arange(n)] = np.inf
+        c2 = r2.min(0)
+        c = Dp[x]
+        shared = np.minimum(c - c1, 0)
+        own = (np.minimum(c, c2) - c1 - shared)[near == i].sum()
+        assert abs(shared.sum() + own - delta) < 1e-9
+        trial = med.copy()
+        trial[i] = x
+        assert abs(ok.total_cost(D, trial, power) - ok.total_cost(D, med, power) - delta) < 1e-9
+    med2, assign, hist = ok.pam(D, med, power=2, max_swaps=30)
+    assert all(b < a for a, b in zip(hist, hist[1:])) and len(set(med2.tolist())) == K
+    assert (assign == np.argmin(D[med2], axis=0)).all()
+
+
+def test_faiss_semantics_restatement_shapes_and_self_column():
+    """oracle/knn.py: build_knn_graph_faiss_semantics (IndexFlatL2 / IndexFlatIP restated; unpinned): squared float32
+    distances, self column dropped when it leads every row, symmetric graph without diagonal."""
+    from oracle import knn as okn
+    z = latents(120, 8, 4)
+    W, info = okn.build_knn_graph_faiss_semantics(z, k=5, metric="euclidean", mode="distance", sym="union")
+    assert info["indices"].shape == (120, 5) and info["distances"].dtype == np.float32
+    d2 = ((z[:, None, :].astype(np.float64) - z[None]) ** 2).sum(-1)
+    np.testing.assert_allclose(info["distances"], np.sort(d2, axis=1)[:, 1:6], rtol=1e-6)
+    assert (W - W.T).nnz == 0 and W.diagonal().sum() == 0
+    Wc, ic = okn.build_knn_graph_faiss_semantics(z, k=5, metric="cosine", mode="connectivity", sym="mutual")
+    assert set(np.unique(Wc.data)) <= {1.0} and ic["distances"].min() > -1e-6
+    with pytest.raises(ValueError):
+        okn.build_knn_graph_faiss_semantics(z, k=5, metric="manhattan")
