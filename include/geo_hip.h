@@ -133,13 +133,12 @@ int geo_rows_argmin(const float *D, int64_t ld, const int32_t *rows, int32_t n_r
                     float *dmin_out, int32_t *argmin_out, void *stream);
 /* geo_pam_swap_deltas: PAM's SWAP evaluation over the resident matrix (extension; FastPAM1 form).  For every
  * non-medoid candidate x: the medoid whose replacement by x lowers the total cost sum_j D[nearest(j)][j]^power most (first
- * medoid on ties) and that change.  order / offsets: nodes grouped by their nearest medoid (ascending node index inside a
- * group); member_cluster i32 [n]: the group of order[m]; c1_members / c2_members f64 [n]: cost (D^power) of the nearest /
- * second-nearest medoid of order[m], in that member order; is_medoid u8 [n].  best_delta_out f64 [n] (+inf for medoids), best_medoid_out i32 [n] (position in 0..K-1).
- * Reads D exactly once (n^2 * 4 bytes): HBM-bound. */
-int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *order, const int32_t *offsets, const int32_t *member_cluster,
-                        const double *c1_members, const double *c2_members, const uint8_t *is_medoid, int32_t n, int32_t K,
-                        int32_t power, double *best_delta_out, int32_t *best_medoid_out, void *stream);
+ * medoid on ties) and that change.  nearest i32 [n]: position (0..K-1) of every node's nearest medoid; c1 / c2 f64 [n]: cost
+ * (D^power) of its nearest / second-nearest medoid; is_medoid u8 [n].  best_delta_out f64 [n] (+inf for medoids),
+ * best_medoid_out i32 [n] (position in 0..K-1).  Reads D exactly once, row by row (n^2 * 4 bytes): HBM-bound.  K <= 3584. */
+int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const double *c1, const double *c2,
+                        const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power, double *best_delta_out,
+                        int32_t *best_medoid_out, void *stream);
 /* geo_attach_argmin: geodesic assignment of points outside the graph (the step the reference's notes call
  * assign_codes_val_geodesic.py, docs/results/cifar10_quantization_analysis.md:147; not in its repository).  Point v is
  * joined to graph nodes nbr[v][0..k) by edges of length len[v][0..k) (nbr < 0: no edge); Dt f32 [n][ld] holds the medoids'

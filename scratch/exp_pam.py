@@ -22,16 +22,13 @@ lib = _lib.load()
 dmin, near = assign_from_rows_device(D, m); near = near.long()
 c1 = dmin.double() ** 2
 rows = D[m.long()].double() ** 2; rows.scatter_(0, near[None, :], float("inf")); c2 = rows.min(dim=0).values
-order = torch.argsort(near, stable=True)
-offsets = torch.zeros(K + 1, dtype=torch.int32, device=dev); offsets[1:] = torch.cumsum(torch.bincount(near, minlength=K), 0).to(torch.int32)
 is_med = torch.zeros(n, dtype=torch.uint8, device=dev); is_med[m.long()] = 1
-c1m, c2m, o32 = c1[order].contiguous(), c2[order].contiguous(), order.to(torch.int32).contiguous()
-mc = near[order].to(torch.int32).contiguous()
+n32 = near.to(torch.int32).contiguous()
 best = torch.empty(n, dtype=torch.float64, device=dev); which = torch.empty(n, dtype=torch.int32, device=dev)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for rep in range(3):
     e0.record()
-    _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(o32), ptr(offsets), ptr(mc), ptr(c1m), ptr(c2m), ptr(is_med), n, K, 2, ptr(best), ptr(which), stream_ptr()), "pam")
+    _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(n32), ptr(c1), ptr(c2), ptr(is_med), n, K, 2, ptr(best), ptr(which), stream_ptr()), "pam")
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print(f"kernel alone {ms:.2f} ms = {n * n * 4 / ms / 1e6:.0f} GB/s of matrix bytes")

@@ -18,6 +18,7 @@ const OptionName kOptionNames[] = {
     {"sssp_trace", "GEO_SSSP_TRACE", &Options::sssp_trace},
     {"sssp_u32", "GEO_SSSP_U32", &Options::sssp_u32},
     {"sssp_push", "GEO_SSSP_PUSH", &Options::sssp_push},
+    {"sssp_order", "GEO_SSSP_ORDER", &Options::sssp_order},
     {"sssp_delta", "GEO_SSSP_DELTA", &Options::sssp_delta},
     {"sssp_push_blocks", "GEO_SSSP_PUSH_BLOCKS", &Options::sssp_push_blocks},
     {"sssp_push_persistent", "GEO_SSSP_PUSH_PERSISTENT", &Options::sssp_push_persistent},

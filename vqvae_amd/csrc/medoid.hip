@@ -95,116 +95,59 @@ __global__ __launch_bounds__(256) void attach_argmin_kernel(const float *__restr
 // replaced by x is
 //   dTD(i, x) = sum_j min(c(x,j) - c1(j), 0)  +  sum_{j: nearest(j) = i} [ min(c(x,j), c2(j)) - c1(j) - min(c(x,j) - c1(j), 0) ]
 // with c = D^power, c1 / c2 = cost to the nearest / second-nearest medoid -- all K medoids from ONE pass over row x.
-// One workgroup per candidate; a wave takes whole clusters (members = order[offsets[i] .. offsets[i+1]), ascending node
-// index; c1 / c2 are given in that member order, so they stream), lane-strided fp64 sums + xor butterfly = a fixed summation
-// tree; the cluster terms are then combined in cluster order by thread 0.  Output per candidate: its best medoid to replace
-// (first index on ties) and the change.  The matrix is read exactly once per pass: N^2 x 4 bytes, HBM-bound.
-__global__ __launch_bounds__(256) void pam_swap_kernel(const float *__restrict__ D, int64_t ld, const int32_t *__restrict__ order,
-                                                      const int32_t *__restrict__ offsets, const double *__restrict__ c1m,
-                                                      const double *__restrict__ c2m, const uint8_t *__restrict__ is_medoid,
-                                                      int32_t n, int32_t K, int32_t power, double *__restrict__ best_delta,
-                                                      int32_t *__restrict__ best_medoid) {
-    extern __shared__ double sh[];                             // A[K] (shared term per cluster), B[K] (own-cluster term)
-    double *A = sh, *B = sh + K;
+// One workgroup per candidate row, streamed in its natural order (coalesced: the matrix is read exactly once per pass,
+// n^2 * 4 bytes, HBM-bound; nearest / c1 / c2 are 1.2 MB shared by all rows and stay in the L2).  Each wave takes a quarter of
+// the row and adds its terms to ITS OWN per-medoid accumulators in LDS (ds_add_f64; program order inside a wave), the four
+// waves' accumulators are combined in wave order, thread 0 picks the best medoid (first on ties).
+// (Two earlier forms walked the row in cluster-sorted member order to sum each cluster with a fixed tree: the gather into the
+// row re-fetched every 128-byte line ~30 times from HBM -- 54 ms per pass at 60 000 x 60 000 instead of 4.)
+template <bool PER_WAVE>
+__global__ __launch_bounds__(256) void pam_swap_kernel(const float *__restrict__ D, int64_t ld, const int32_t *__restrict__ nearest,
+                                                      const double *__restrict__ c1v, const double *__restrict__ c2v,
+                                                      const uint8_t *__restrict__ is_medoid, int32_t n, int32_t K, int32_t power,
+                                                      double *__restrict__ best_delta, int32_t *__restrict__ best_medoid) {
+    extern __shared__ double sh[];                             // PER_WAVE: [4][2][K]; else [2][K] shared by the waves
     const int64_t x = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (is_medoid[x]) {                                        // (block-uniform) a medoid is no candidate
         if (threadIdx.x == 0) { best_delta[x] = __longlong_as_double(0x7ff0000000000000LL); best_medoid[x] = 0; }
         return;
     }
-    const float *row = D + x * ld;
-    for (int32_t i = wave; i < K; i += 4) {
-        const int32_t m0 = offsets[i], m1 = offsets[i + 1];
-        double a = 0.0, b = 0.0;
-        for (int32_t m = m0 + lane; m < m1; m += 64) {
-            const double d = (double)row[order[m]];
-            const double c = power == 2 ? d * d : d;
-            const double c1 = c1m[m], c2 = c2m[m];
-            const double shared = fmin(c - c1, 0.0);
-            a += shared;
-            b += fmin(c, c2) - c1 - shared;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (lane == 0) { A[i] = a; B[i] = b; }
-    }
+    const int copies = PER_WAVE ? 4 : 1;
+    for (int i = threadIdx.x; i < copies * 2 * K; i += 256) sh[i] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double all = 0.0;
-        for (int32_t i = 0; i < K; ++i) all += A[i];           // cluster order
-        double best = __longlong_as_double(0x7ff0000000000000LL);
-        int32_t arg = 0;
-        for (int32_t i = 0; i < K; ++i) {
-            const double dtd = all + B[i];
-            if (dtd < best) { best = dtd; arg = i; }           // strict: the first medoid wins ties
-        }
-        best_delta[x] = best;
-        best_medoid[x] = arg;
-    }
-}
-
-// The same evaluation with the row streamed in MEMBER order (members sorted by cluster): every wave takes a quarter of the
-// member list in blocks of 64 consecutive members -- order / cluster / c1 / c2 coalesced, one gather into the row per member,
-// several blocks in flight -- and reduces each block by a segmented inclusive scan over the lanes (a cluster is a contiguous
-// run of lanes; Hillis-Steele, fixed order); the last lane of every run adds the run's sums to the wave's own per-cluster
-// accumulators in LDS (runs of one block hit distinct clusters; blocks follow each other in program order), and the four
-// waves' accumulators are combined in wave order.  Deterministic like the kernel above, ~10x its speed at K = 512 (that
-// one walks 128 clusters per wave one after the other: latency-bound at 0.25 TB/s of matrix bytes).
-__global__ __launch_bounds__(256) void pam_swap_stream_kernel(const float *__restrict__ D, int64_t ld, const int32_t *__restrict__ order,
-                                                             const int32_t *__restrict__ member_cluster,
-                                                             const double *__restrict__ c1m, const double *__restrict__ c2m,
-                                                             const uint8_t *__restrict__ is_medoid, int32_t n, int32_t K,
-                                                             int32_t power, double *__restrict__ best_delta,
-                                                             int32_t *__restrict__ best_medoid) {
-    extern __shared__ double sh[];                             // [4 waves][2][K]
-    const int64_t x = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (is_medoid[x]) {
-        if (threadIdx.x == 0) { best_delta[x] = __longlong_as_double(0x7ff0000000000000LL); best_medoid[x] = 0; }
-        return;
-    }
-    for (int i = threadIdx.x; i < 8 * K; i += 256) sh[i] = 0.0;
-    __syncthreads();
-    double *Aw = sh + (size_t)wave * 2 * K, *Bw = Aw + K;
+    double *Aw = sh + (PER_WAVE ? (size_t)wave * 2 * K : 0), *Bw = Aw + K;
     const float *row = D + x * ld;
     const int32_t blocks = (n + 63) / 64, per = (blocks + 3) / 4;
     const int32_t b0 = wave * per, b1 = (b0 + per < blocks) ? b0 + per : blocks;
     for (int32_t blk = b0; blk < b1; ++blk) {
-        const int32_t m = blk * 64 + lane;
-        const bool valid = m < n;
-        int32_t cl = K;                                       // sentinel: its own run, never stored
-        double a = 0.0, b = 0.0;
-        if (valid) {
-            cl = member_cluster[m];
-            const double d = (double)row[order[m]];
+        const int32_t j = blk * 64 + lane;
+        if (j < n) {
+            const double d = (double)row[j];
             const double c = power == 2 ? d * d : d;
-            const double c1 = c1m[m], c2 = c2m[m];
-            a = fmin(c - c1, 0.0);
-            b = fmin(c, c2) - c1 - a;
+            const double c1 = c1v[j], c2 = c2v[j];
+            const int32_t cl = nearest[j];
+            const double a = fmin(c - c1, 0.0);
+            const double b = fmin(c, c2) - c1 - a;
+            if (a != 0.0) atomicAdd(&Aw[cl], a);
+            if (b != 0.0) atomicAdd(&Bw[cl], b);
         }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {              // segmented inclusive scan: a run = equal cluster ids
-            const double a2 = __shfl_up(a, off, 64), b2 = __shfl_up(b, off, 64);
-            const int32_t c2l = __shfl_up(cl, off, 64);
-            if (lane >= off && c2l == cl) { a += a2; b += b2; }
-        }
-        const int32_t nxt = __shfl_down(cl, 1, 64);
-        if (valid && (lane == 63 || nxt != cl)) { Aw[cl] += a; Bw[cl] += b; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K; i += 256) {              // waves in order
-        sh[i] = ((sh[i] + sh[2 * K + i]) + sh[4 * K + i]) + sh[6 * K + i];
-        sh[K + i] = ((sh[K + i] + sh[3 * K + i]) + sh[5 * K + i]) + sh[7 * K + i];
-    }
+    if (PER_WAVE)
+        for (int i = threadIdx.x; i < K; i += 256) {          // waves in order
+            sh[i] = ((sh[i] + sh[2 * K + i]) + sh[4 * K + i]) + sh[6 * K + i];
+            sh[K + i] = ((sh[K + i] + sh[3 * K + i]) + sh[5 * K + i]) + sh[7 * K + i];
+        }
     __syncthreads();
     if (threadIdx.x == 0) {
         double all = 0.0;
-        for (int32_t i = 0; i < K; ++i) all += sh[i];
+        for (int32_t i = 0; i < K; ++i) all += sh[i];          // medoid order
         double best = __longlong_as_double(0x7ff0000000000000LL);
         int32_t arg = 0;
         for (int32_t i = 0; i < K; ++i) {
             const double dtd = all + sh[K + i];
-            if (dtd < best) { best = dtd; arg = i; }
+            if (dtd < best) { best = dtd; arg = i; }           // strict: the first medoid wins ties
         }
         best_delta[x] = best;
         best_medoid[x] = arg;
@@ -213,20 +156,19 @@ __global__ __launch_bounds__(256) void pam_swap_stream_kernel(const float *__res
 
 }  // namespace
 
-extern "C" int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *order, const int32_t *offsets, const int32_t *member_cluster,
-                                   const double *c1_members, const double *c2_members, const uint8_t *is_medoid, int32_t n, int32_t K,
-                                   int32_t power, double *best_delta_out, int32_t *best_medoid_out, void *stream_) {
+extern "C" int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const double *c1, const double *c2,
+                                   const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power, double *best_delta_out,
+                                   int32_t *best_medoid_out, void *stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    GEO_REQUIRE(D && order && offsets && member_cluster && c1_members && c2_members && is_medoid && best_delta_out && best_medoid_out,
-                "geo_pam_swap_deltas: null pointer");
-    GEO_REQUIRE(n > 0 && K > 0 && K <= 4096 && ld >= n && (power == 1 || power == 2), "geo_pam_swap_deltas: bad n=%d K=%d ld=%lld power=%d",
+    GEO_REQUIRE(D && nearest && c1 && c2 && is_medoid && best_delta_out && best_medoid_out, "geo_pam_swap_deltas: null pointer");
+    GEO_REQUIRE(n > 0 && K > 0 && K <= 3584 && ld >= n && (power == 1 || power == 2), "geo_pam_swap_deltas: bad n=%d K=%d ld=%lld power=%d",
                 n, K, (long long)ld, power);
-    if (K <= 896)            // 8 K doubles of LDS per workgroup (<= 56 KB): the streaming kernel
-        pam_swap_stream_kernel<<<(unsigned)n, 256, 8 * (size_t)K * sizeof(double), stream>>>(D, ld, order, member_cluster, c1_members, c2_members,
-                                                                                           is_medoid, n, K, power, best_delta_out, best_medoid_out);
-    else
-        pam_swap_kernel<<<(unsigned)n, 256, 2 * (size_t)K * sizeof(double), stream>>>(D, ld, order, offsets, c1_members, c2_members, is_medoid,
-                                                                                    n, K, power, best_delta_out, best_medoid_out);
+    if (K <= 896)            // 8 K doubles of LDS per workgroup (<= 56 KB): accumulators per wave, combined in wave order
+        pam_swap_kernel<true><<<(unsigned)n, 256, 8 * (size_t)K * sizeof(double), stream>>>(D, ld, nearest, c1, c2, is_medoid, n, K, power,
+                                                                                          best_delta_out, best_medoid_out);
+    else                     // one pair of accumulators for the workgroup (sums then depend on the waves' interleaving: ~1e-16 relative)
+        pam_swap_kernel<false><<<(unsigned)n, 256, 2 * (size_t)K * sizeof(double), stream>>>(D, ld, nearest, c1, c2, is_medoid, n, K, power,
+                                                                                           best_delta_out, best_medoid_out);
     GEO_LAUNCH_CHECK();
     return GEO_OK;
 }

@@ -1077,6 +1077,10 @@ int solve_single(const int32_t *indptr, const int32_t *indices, const float *wei
     return GEO_OK;
 }
 
+__global__ void gather_i32_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ at, int32_t m, int32_t *__restrict__ out) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = a[at[i]];
+}
+
 __global__ void gather_f32_kernel(const double *__restrict__ d, const int32_t *__restrict__ at, int32_t m,
                                   float *__restrict__ out) {
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = (float)d[at[i]];
@@ -1096,6 +1100,49 @@ __global__ __launch_bounds__(256) void max_finite_kernel(const double *__restric
     }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
+
+// ---- ordering the sources by the cells of the graph they sit in (cheap replacement of two landmark solves) --------------
+// Multi-source BFS by hop count: label[v] = position of the source whose front reaches v first (ties: the first neighbour in
+// CSR order that was reached one level earlier); one launch per level, a level only reads level - 1.
+__global__ __launch_bounds__(256) void cell_seed_kernel(const int32_t *__restrict__ src, int32_t n_sources, int32_t n,
+                                                       int32_t *__restrict__ label, int32_t *__restrict__ level_of,
+                                                       int32_t *__restrict__ cell_of_source) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sources; i += gridDim.x * blockDim.x) {
+        const int32_t v = src[i];
+        if (v < 0 || v >= n) continue;
+        atomicMin(reinterpret_cast<unsigned *>(&label[v]), (unsigned)i);      // repeated sources: the first position owns the cell
+        level_of[v] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void cell_grow_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int32_t n,
+                                                       int32_t *label, int32_t *level_of, int32_t level, int32_t *__restrict__ changed) {
+    bool any = false;
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        if (level_of[v] >= 0) continue;
+        for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+            const int32_t u = indices[e];
+            if (level_of[u] == level - 1) {
+                label[v] = label[u];
+                level_of[v] = level;
+                any = true;
+                break;
+            }
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+__global__ __launch_bounds__(256) void cell_adjacency_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int32_t n,
+                                                            const int32_t *__restrict__ label, int32_t words, uint32_t *__restrict__ adj) {
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const int32_t lv = label[v];
+        if (lv < 0) continue;
+        for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+            const int32_t lu = label[indices[e]];
+            if (lu >= 0 && lu != lv) atomicOr(&adj[(size_t)lv * words + (lu >> 5)], 1u << (lu & 31));
+        }
+    }
+}
+constexpr int32_t CELL_ORDER_MAX_SOURCES = 16384;       // quotient graph as a bitmap: 32 MB at this size
 
 struct MultiWs {
     double *dist;
@@ -1134,7 +1181,8 @@ size_t chunk_bytes(int32_t n, int64_t nnz, int32_t nb) {
     return 2 * geo::align_up(((size_t)n + 1) * 4) + 2 * geo::align_up(max_chunks * 4) +
            geo::align_up(geo::scan_tmp_bytes((int64_t)n + 1)) + geo::align_up(3 * (size_t)nb * words * 4) +
            geo::align_up(4 * (((size_t)nb + 31) / 32 * 32) * 4) + geo::align_up((size_t)n * 8) + geo::align_up(2 * (size_t)nb * 16 * 4) +
-           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024 + push_bytes(n, nnz, nb);
+           geo::align_up((size_t)(nnz > 0 ? nnz : 1) * 4) + 256 + 256 + geo::align_up((size_t)n * 4) + 1024 + push_bytes(n, nnz, nb) +
+           geo::align_up((size_t)std::min(nb * 16, CELL_ORDER_MAX_SOURCES) * ((std::min(nb * 16, CELL_ORDER_MAX_SOURCES) + 31) / 32) * 4);
 }
 
 // slots of a solve: whole batches of `sb` sources, and (for the 32-source fixed-point layout of the same buffers) of 32
@@ -1202,6 +1250,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     int32_t *chunk_cnt = nullptr, *row_order = nullptr;
     PushState push{};
     int32_t *team_ctl = nullptr;
+    uint32_t *cell_adj = nullptr;
     double *wsum = nullptr;
     const geo::Options &opt = geo::options();
     const int act_mode = opt.sssp_act;
@@ -1245,10 +1294,14 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         push.theta = ar.take<double>(2 * (size_t)cs);
         push.active = ar.take<int32_t>(64);
         team_ctl = ar.take<int32_t>(512);
+        {
+            const size_t S = (size_t)std::min(nb * 16, CELL_ORDER_MAX_SOURCES);
+            cell_adj = ar.take<uint32_t>(S * ((S + 31) / 32));
+        }
         wsum = ar.take<double>(8);
         GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange && push.near_lists &&
                         push.far_lists && push.near_bits && push.far_bits && push.near_cnt && push.far_cnt && push.far_slot &&
-                        push.theta && push.active && team_ctl && wsum,
+                        push.theta && push.active && team_ctl && cell_adj && wsum,
                     "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
@@ -1274,10 +1327,77 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         GEO_HIP_CHECK(hipEventCreate(&g_ev0));
         GEO_HIP_CHECK(hipEventCreate(&g_ev1));
     }
-    // ---- order the sources along two landmark distances (see below: "Sources that lie close together ...") ----
+    // ---- order the sources so that a batch holds neighbouring ones (see below: "Sources that lie close together ...") ----
     bool grouped = false;
     double landmark_ecc = 0.0;
+    // (a) by the cells of the graph (`sssp_order=1`, experiment): multi-source BFS by hops gives every node the source it is
+    //     nearest to; two sources are adjacent when an edge joins their cells; sources are taken in BFS order over that K-node
+    //     quotient graph (host).  ~20 launches over the graph and one K x K bitmap: 0.3 ms at 60 000 nodes / 512 sources,
+    //     against 5.8 ms for the two exact single-source solves of (b) on the swiss bench graph (288 sweeps each) -- but the
+    //     batches it forms are worse: the push solve then takes 36.9 ms instead of 20.5 ms (measured), so (b) is the default.
+    auto order_by_cells = [&]() -> int {
+        int32_t *label = reinterpret_cast<int32_t *>(lm_d), *level_of = label + n;            // lm_d: n doubles
+        const int32_t wordsK = (n_sources + 31) / 32;
+        GEO_HIP_CHECK(hipMemsetAsync(label, 0xff, 2 * (size_t)n * sizeof(int32_t), stream));    // -1 everywhere
+        GEO_HIP_CHECK(hipMemsetAsync(cell_adj, 0, (size_t)n_sources * wordsK * 4, stream));
+        cell_seed_kernel<<<geo::grid_for(n_sources, 256, 64), 256, 0, stream>>>(sources, n_sources, n, label, level_of, nullptr);
+        GEO_LAUNCH_CHECK();
+        int32_t level = 1, hchanged = 1;
+        while (hchanged && level < n + 2) {
+            GEO_HIP_CHECK(hipMemsetAsync(lm_flags, 0, sizeof(int32_t), stream));
+            for (int g = 0; g < 8; ++g, ++level) {
+                if (g == 7) GEO_HIP_CHECK(hipMemsetAsync(lm_flags, 0, sizeof(int32_t), stream));   // the group's last level decides
+                cell_grow_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, indices, n, label, level_of, level, lm_flags);
+            }
+            GEO_LAUNCH_CHECK();
+            GEO_HIP_CHECK(hipMemcpyAsync(&hchanged, lm_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        cell_adjacency_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, indices, n, label, wordsK, cell_adj);
+        GEO_LAUNCH_CHECK();
+        std::vector<uint32_t> adj((size_t)n_sources * wordsK);
+        std::vector<int32_t> cell(n_sources);
+        gather_i32_kernel<<<geo::grid_for(n_sources, 256, 64), 256, 0, stream>>>(label, sources, n_sources, reinterpret_cast<int32_t *>(lm_key));
+        GEO_HIP_CHECK(hipMemcpyAsync(adj.data(), cell_adj, adj.size() * 4, hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipMemcpyAsync(cell.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        // BFS over the quotient graph from the cell of sources[0]; unreached cells (other components) start new searches
+        std::vector<int32_t> rank(n_sources, -1), queue;
+        queue.reserve(n_sources);
+        int32_t next_rank = 0;
+        auto search = [&](int32_t start) {
+            size_t head = queue.size();
+            queue.push_back(start);
+            rank[start] = next_rank++;
+            while (head < queue.size()) {
+                const int32_t c = queue[head++];
+                const uint32_t *row = adj.data() + (size_t)c * wordsK;
+                for (int32_t wi = 0; wi < wordsK; ++wi) {
+                    uint32_t bits = row[wi];
+                    while (bits) {
+                        const int32_t d = wi * 32 + __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (d < n_sources && rank[d] < 0) { rank[d] = next_rank++; queue.push_back(d); }
+                    }
+                }
+            }
+        };
+        search(cell[0] >= 0 ? cell[0] : 0);
+        for (int32_t i = 0; i < n_sources; ++i) {
+            const int32_t c = cell[i] >= 0 ? cell[i] : i;
+            if (rank[c] < 0) search(c);
+        }
+        std::vector<uint64_t> key(n_sources);
+        for (int32_t i = 0; i < n_sources; ++i) key[i] = ((uint64_t)(uint32_t)rank[cell[i] >= 0 ? cell[i] : i] << 32) | (uint32_t)i;
+        std::sort(key.begin(), key.end());
+        for (int32_t i = 0; i < n_sources; ++i) order[i] = (int32_t)(key[i] & 0xffffffffu);
+        grouped = true;
+        return GEO_OK;
+    };
+    // (b) along two landmark distances (round 2; `sssp_order=0`, the default): Morton order of (dist from sources[0], dist from the source
+    //     farthest from it).  Also yields the eccentricity of sources[0], which tells the 32-bit solve early that it cannot fit.
     auto regroup_sources = [&]() -> int {
+        if (opt.sssp_order != 0 && n_sources <= CELL_ORDER_MAX_SOURCES) return order_by_cells();
         int32_t lm_sweeps = 0;
         std::vector<float> ka(n_sources), kb(n_sources);
         const int gk = geo::grid_for(n_sources, 256, 64);
@@ -1417,7 +1537,9 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                         // some node is landmark_ecc away from sources[0]: if that alone does not fit 32 bits of units the
                         // fixed-point solve would only find out at its end -- the fp64 kernels take the (ordered) sources now
                         if (landmark_ecc / unit >= 4294967294.0) give_up = true;
-                        if (opt.sssp_push == 3) give_up = true;        // (experiment: ordered sources always take the push solve)
+                        // ordered by cells (no eccentricity known): long geodesics go to the near-far push solve, which is at
+                        // least as fast as the ordered fixed-point sweeps and cannot overflow
+                        if (opt.sssp_push != 0 && (opt.sssp_order != 0 || opt.sssp_push == 3)) give_up = true;
                     }
                 }
                 if (!done && sweeps > (int64_t)n + 2) give_up = true;

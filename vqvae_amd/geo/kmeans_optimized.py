@@ -429,18 +429,14 @@ def pam_swap_pass_device(D: torch.Tensor, medoids: torch.Tensor, power: int = 2)
         del rows
     else:
         c2 = torch.full_like(c1, float("inf"))
-    order = torch.argsort(near, stable=True)
-    offsets = torch.zeros(K + 1, dtype=torch.int32, device=dev)
-    offsets[1:] = torch.cumsum(torch.bincount(near, minlength=K), 0).to(torch.int32)
     is_med = torch.zeros(n, dtype=torch.uint8, device=dev)
     is_med[med] = 1
-    c1m, c2m, order32 = c1[order].contiguous(), c2[order].contiguous(), order.to(torch.int32).contiguous()
-    member_cluster = near[order].to(torch.int32).contiguous()
+    near32, c1, c2 = near.to(torch.int32).contiguous(), c1.contiguous(), c2.contiguous()
     best = torch.empty(n, dtype=torch.float64, device=dev)
     which = torch.empty(n, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(order32), ptr(offsets), ptr(member_cluster), ptr(c1m), ptr(c2m), ptr(is_med), n, K,
-                                           int(power), ptr(best), ptr(which), stream_ptr()), "geo_pam_swap_deltas")
+        _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(near32), ptr(c1), ptr(c2), ptr(is_med), n, K, int(power),
+                                           ptr(best), ptr(which), stream_ptr()), "geo_pam_swap_deltas")
     delta = best.min()
     x = int(torch.nonzero(best == delta)[0])                         # lowest candidate among equal changes
     return float(delta), int(which[x]), x, float(c1.sum())
