@@ -128,3 +128,51 @@ def test_data_parallel_run_equals_single_process(tmp_path, world):
         np.testing.assert_allclose(got["train"], hist["train_loss"], rtol=1e-5)
         np.testing.assert_allclose(got["val"], hist["val_loss"], rtol=1e-5)
         np.testing.assert_allclose(got["norms"], norms, rtol=1e-5)
+
+
+def _dp_dropout_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vqvae_amd.prior.codes_dataset import get_code_loaders
+    from vqvae_amd.prior.train import seed_dropout_stream, train_prior
+    from vqvae_amd.prior.transformer import Transformer
+    from vqvae_amd.scripts.train_transformer import set_seed
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        set_seed(42)
+        shuffler = torch.Generator()
+        shuffler.manual_seed(42)
+        tl, vl = get_code_loaders(os.path.join(tmp, "codes.npy"), os.path.join(tmp, "y.pt"), batch_size=96, num_workers=0,
+                                  pin_memory=False, generator=shuffler)
+        model = Transformer(**dict(PRIOR_CFG, dropout=0.2))
+        seed_dropout_stream(42, rank, torch.device("cpu"))
+        seen = []
+        orig_iter = tl._order
+
+        def spy():
+            o = orig_iter()
+            seen.append(o[:8].tolist())
+            return o
+        tl._order = spy
+        hist = train_prior(model, tl, vl, epochs=2, lr=3e-4, weight_decay=0.01, device=torch.device("cpu"))
+        first_mask = torch.rand(4).tolist()                                   # the rank's own stream continues differently
+        np.savez(os.path.join(tmp, f"drop{rank}.npz"), train=np.array(hist["train_loss"]), arena=model.arena.detach().numpy(),
+                 order=np.array(seen), probe=np.array(first_mask))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_with_dropout_keeps_the_ranks_in_step(tmp_path):
+    """dropout > 0 under data parallelism (advisor, round 2): the shuffling has its own generator, seeded identically on
+    every rank, so the ranks walk the same batches whatever their dropout streams do; each rank draws its masks from its own
+    stream; the all-reduced gradients keep the weights identical on all ranks."""
+    write_prior_inputs(str(tmp_path))
+    mp.spawn(_dp_dropout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(os.path.join(str(tmp_path), f"drop{r}.npz")) for r in range(2))
+    np.testing.assert_array_equal(a["order"], b["order"])                     # same batches on both ranks, both epochs
+    np.testing.assert_array_equal(a["arena"], b["arena"])                     # identical weights after every all-reduce
+    np.testing.assert_array_equal(a["train"], b["train"])
+    assert np.isfinite(a["train"]).all() and a["train"][-1] < a["train"][0]
+    assert not np.array_equal(a["probe"], b["probe"])                         # ... while the dropout streams differ
