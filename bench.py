@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- latents/s through the geodesic-codebook hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss|real|c5cb|c5prior]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c3d32|c4|swiss|real|c5cb|c5prior|c2pam]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU
@@ -55,6 +55,7 @@ WORKLOADS = {
     "real": (960000, 16, 1, 28, 20, 512),       # FashionMNIST: 60 000 images x 4x4 cells, d=16, K=512
     "c5cb": (800000, 32, 3, 32, 20, 512),       # CIFAR-10 (BASELINE config 5's codebook stage): 50 000 x 4x4 cells, d=32, 32-px decoder
     "c5prior": None,                            # BASELINE config 5's second stage: prior training tokens/s (prior_bench)
+    "c2pam": None,                              # extension: dense all-pairs matrix + PAM swap sweeps over it (pam_bench)
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak = half the 157.3 TFLOP/s f32 vector peak of MI355X_MICROARCH.md
@@ -289,6 +290,67 @@ def prior_bench(args, rank, world, dev, json_fd):
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+def pam_bench(args, dev, json_fd):
+    """Secondary line (--workload c2pam): the DENSE form of north_star's "APSP + K-medoids sweep" at configs[1]'s size --
+    the all-pairs geodesic matrix of the 60 000-latent graph (14.4 GB, resident) and PAM swap evaluations over it.  An
+    extension (the reference has neither): parity is against oracle/kmedoids.py's restatements in tests/.
+    One step = one swap evaluation (all 512 x 59 488 exchanges): it reads the matrix exactly once, so the roofline is
+    n^2 * 4 bytes / kernel time against 8 TB/s."""
+    from vqvae_amd import _lib
+    from vqvae_amd.geo.geo_shortest_paths import all_pairs_geodesic_device
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized, pam_swap_pass_device
+    from vqvae_amd.geo.knn_graph_optimized import knn_graph_device
+    n, d, k, K = 60000, 16, 20, 512
+    z = torch.from_numpy(np.random.RandomState(0).randn(n, d).astype(np.float32)).to(dev)
+    with contextlib.redirect_stdout(sys.stderr):
+        G, _, _ = knn_graph_device(z, k, mode="distance", sym="union")
+        med, _, _ = fit_kmedoids_optimized(G, K=K, init="kpp", seed=42)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        D = all_pairs_geodesic_device(G)
+        torch.cuda.synchronize(dev)
+        t_apsp = time.perf_counter() - t0
+        m = torch.from_numpy(med.astype(np.int32)).to(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kernel_ms = []
+        orig = _lib.load().geo_pam_swap_deltas
+
+        def timed(*a):                                   # HIP events on the stream the kernel is launched on
+            e0.record()
+            rc = orig(*a)
+            e1.record()
+            e1.synchronize()
+            kernel_ms.append(e0.elapsed_time(e1))
+            return rc
+
+        for _ in range(args.warmup):
+            pam_swap_pass_device(D, m, 2)
+        torch.cuda.synchronize(dev)
+        _lib.load().geo_pam_swap_deltas = timed
+        try:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                delta, i, x, total = pam_swap_pass_device(D, m, 2)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        finally:
+            _lib.load().geo_pam_swap_deltas = orig
+    bytes_per_pass = float(n) * n * 4
+    avg_kernel = sum(kernel_ms) / len(kernel_ms)
+    achieved = bytes_per_pass / (avg_kernel * 1e-3) / 1e9
+    out = {"metric": "PAM swap evaluations/sec over the dense 60 000 x 60 000 geodesic matrix (extension; secondary line)",
+           "value": args.steps / dt, "unit": "swap passes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 sums of f32 distances",
+           "data": "synthetic", "config": {"workload": f"c2pam: N={n} d={d} k={k} K={K}, Euclidean kNN graph, power 2", "all_pairs_fill_s": t_apsp,
+                                           "matrix_GB": bytes_per_pass / 1e9},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "pam_swap_kernel", "launches_per_step": 1, "avg_launch_ms": avg_kernel,
+                        "algorithmic_bytes_per_launch": bytes_per_pass},
+           "best_swap": {"delta": delta, "medoid_position": i, "candidate": x, "total_cost": total}}
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def free_port() -> int:
     import socket
     with socket.socket() as s:
@@ -353,6 +415,10 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    if args.workload == "c2pam":
+        assert world == 1, "c2pam is a one-GPU line"
+        pam_bench(args, dev, json_fd)
+        return
     if args.workload == "c5prior":
         prior_bench(args, rank, world, dev, json_fd)
         if world > 1:

@@ -133,11 +133,12 @@ int geo_rows_argmin(const float *D, int64_t ld, const int32_t *rows, int32_t n_r
                     float *dmin_out, int32_t *argmin_out, void *stream);
 /* geo_pam_swap_deltas: PAM's SWAP evaluation over the resident matrix (extension; FastPAM1 form).  For every
  * non-medoid candidate x: the medoid whose replacement by x lowers the total cost sum_j D[nearest(j)][j]^power most (first
- * medoid on ties) and that change.  nearest i32 [n]: position (0..K-1) of every node's nearest medoid; c1 / c2 f64 [n]: cost
- * (D^power) of its nearest / second-nearest medoid; is_medoid u8 [n].  best_delta_out f64 [n] (+inf for medoids),
+ * medoid on ties) and that change.  nearest i32 [n]: position (0..K-1) of every node's nearest medoid; d1 / d2 f32 [n]:
+ * distance to its nearest / second-nearest medoid; base f64 [K]: sum over the nodes of medoid i of (d2^power - d1^power);
+ * is_medoid u8 [n].  K >= 2.  best_delta_out f64 [n] (+inf for medoids),
  * best_medoid_out i32 [n] (position in 0..K-1).  Reads D exactly once, row by row (n^2 * 4 bytes): HBM-bound.  K <= 3584. */
-int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const double *c1, const double *c2,
-                        const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power, double *best_delta_out,
+int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const float *d1, const float *d2,
+                        const double *base, const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power, double *best_delta_out,
                         int32_t *best_medoid_out, void *stream);
 /* geo_attach_argmin: geodesic assignment of points outside the graph (the step the reference's notes call
  * assign_codes_val_geodesic.py, docs/results/cifar10_quantization_analysis.md:147; not in its repository).  Point v is

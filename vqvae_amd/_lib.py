@@ -39,7 +39,7 @@ _SIGNATURES = {
     "geo_kpp_workspace_bytes": (sz, [i32]),
     "geo_cluster_costs": (ctypes.c_int, [c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p]),
     "geo_rows_argmin": (ctypes.c_int, [c_p, i64, c_p, i32, i32, c_p, c_p, c_p]),
-    "geo_pam_swap_deltas": (ctypes.c_int, [c_p, i64, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p]),
+    "geo_pam_swap_deltas": (ctypes.c_int, [c_p, i64, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, c_p, c_p, c_p]),
     "geo_attach_argmin": (ctypes.c_int, [c_p, i64, i32, c_p, c_p, i32, i64, c_p, c_p, c_p]),
     "geo_kpp_resident_max_nodes": (i32, []),
     "geo_kpp_chain": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p, sz, c_p, c_p]),

@@ -92,82 +92,138 @@ __global__ __launch_bounds__(256) void attach_argmin_kernel(const float *__restr
 }
 
 // PAM's SWAP evaluation in the FastPAM1 form: for a candidate x (a row of D) the change of the total cost when medoid i is
-// replaced by x is
-//   dTD(i, x) = sum_j min(c(x,j) - c1(j), 0)  +  sum_{j: nearest(j) = i} [ min(c(x,j), c2(j)) - c1(j) - min(c(x,j) - c1(j), 0) ]
-// with c = D^power, c1 / c2 = cost to the nearest / second-nearest medoid -- all K medoids from ONE pass over row x.
-// One workgroup per candidate row, streamed in its natural order (coalesced: the matrix is read exactly once per pass,
-// n^2 * 4 bytes, HBM-bound; nearest / c1 / c2 are 1.2 MB shared by all rows and stay in the L2).  Each wave takes a quarter of
-// the row and adds its terms to ITS OWN per-medoid accumulators in LDS (ds_add_f64; program order inside a wave), the four
-// waves' accumulators are combined in wave order, thread 0 picks the best medoid (first on ties).
-// (Two earlier forms walked the row in cluster-sorted member order to sum each cluster with a fixed tree: the gather into the
-// row re-fetched every 128-byte line ~30 times from HBM -- 54 ms per pass at 60 000 x 60 000 instead of 4.)
+// replaced by x is, with c = D[x][j]^power and c1(j) <= c2(j) the costs of j's nearest / second-nearest medoid,
+//   dTD(i, x) = sum_j min(c - c1, 0)                                          (x takes j over from its medoid)
+//             + sum_{j: nearest(j) = i} [ min(c, c2) - c1 - min(c - c1, 0) ]  (j loses medoid i: goes to x or to its second)
+// The bracket equals c2 - c1 unless c < c2, so with base[i] = sum_{nearest(j) = i} (c2 - c1) (one small pass per swap
+// evaluation, geo_pam_swap_deltas's `base` argument) it is base[i] + sum_{nearest(j) = i, c < c2} (max(c, c1) - c2): only the
+// few nodes that are closer to x than to their second medoid contribute per-medoid terms.
+// One workgroup per PAIR of candidate rows, streamed in their natural order (coalesced: the matrix is read exactly once per
+// pass, n^2 * 4 bytes, HBM-bound; nearest / d1 / d2 are 12 bytes per node shared by both rows and by all workgroups: they stay
+// in the L2).  The first sum is kept in registers (lane-strided order, wave butterfly, waves in order); the rare per-medoid
+// terms go to the wave's own accumulators in LDS (ds_add_f64; program order inside a wave), combined in wave order; one thread
+// per row picks the best medoid (first on ties).
+// (Earlier forms: cluster-sorted member order with a fixed summation tree per cluster -- the gather into the row re-fetched
+// every 128-byte line ~30 times from HBM, 54 ms per pass at 60 000 x 60 000; natural order with an LDS atomic per (row, node)
+// -- bound by the LDS atomic rate, 9.5 ms.)
+constexpr int PAM_ROWS = 2;
+
 template <bool PER_WAVE>
 __global__ __launch_bounds__(256) void pam_swap_kernel(const float *__restrict__ D, int64_t ld, const int32_t *__restrict__ nearest,
-                                                      const double *__restrict__ c1v, const double *__restrict__ c2v,
-                                                      const uint8_t *__restrict__ is_medoid, int32_t n, int32_t K, int32_t power,
+                                                      const float *__restrict__ d1v, const float *__restrict__ d2v,
+                                                      const double *__restrict__ base, const uint8_t *__restrict__ is_medoid,
+                                                      int32_t n, int32_t K, int32_t power,
                                                       double *__restrict__ best_delta, int32_t *__restrict__ best_medoid) {
-    extern __shared__ double sh[];                             // PER_WAVE: [4][2][K]; else [2][K] shared by the waves
-    const int64_t x = blockIdx.x;
+    extern __shared__ double sh[];                             // B terms: PER_WAVE [4 waves][PAM_ROWS][K], else [PAM_ROWS][K]
+    __shared__ double s_all[4][PAM_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (is_medoid[x]) {                                        // (block-uniform) a medoid is no candidate
-        if (threadIdx.x == 0) { best_delta[x] = __longlong_as_double(0x7ff0000000000000LL); best_medoid[x] = 0; }
-        return;
-    }
+    const int64_t x0 = (int64_t)blockIdx.x * PAM_ROWS;
     const int copies = PER_WAVE ? 4 : 1;
-    for (int i = threadIdx.x; i < copies * 2 * K; i += 256) sh[i] = 0.0;
+    for (int i = threadIdx.x; i < copies * PAM_ROWS * K; i += 256) sh[i] = 0.0;
     __syncthreads();
-    double *Aw = sh + (PER_WAVE ? (size_t)wave * 2 * K : 0), *Bw = Aw + K;
-    const float *row = D + x * ld;
-    const int32_t blocks = (n + 63) / 64, per = (blocks + 3) / 4;
-    const int32_t b0 = wave * per, b1 = (b0 + per < blocks) ? b0 + per : blocks;
-    for (int32_t blk = b0; blk < b1; ++blk) {
-        const int32_t j = blk * 64 + lane;
-        if (j < n) {
-            const double d = (double)row[j];
-            const double c = power == 2 ? d * d : d;
-            const double c1 = c1v[j], c2 = c2v[j];
-            const int32_t cl = nearest[j];
-            const double a = fmin(c - c1, 0.0);
-            const double b = fmin(c, c2) - c1 - a;
-            if (a != 0.0) atomicAdd(&Aw[cl], a);
-            if (b != 0.0) atomicAdd(&Bw[cl], b);
+    double *Bw = sh + (PER_WAVE ? (size_t)wave * PAM_ROWS * K : 0);
+    const float *row[PAM_ROWS];
+    bool live[PAM_ROWS];
+#pragma unroll
+    for (int r = 0; r < PAM_ROWS; ++r) {
+        live[r] = x0 + r < n && !is_medoid[x0 + r];            // a medoid is no candidate
+        row[r] = D + (x0 + (live[r] ? r : 0)) * ld;
+    }
+    double all[PAM_ROWS] = {0.0, 0.0};
+    // a lane takes 4 consecutive nodes per step (16-byte loads of the rows and of d1 / d2 / nearest; four steps in flight)
+    const bool vec = (ld & 3) == 0 && (n & 3) == 0;
+    const int32_t steps = (n + 255) / 256, per = (steps + 3) / 4;
+    const int32_t s0 = wave * per, s1 = (s0 + per < steps) ? s0 + per : steps;
+    auto relax = [&](int r, int32_t j, float dj, float e1f, float e2f, int32_t cl) {
+        const double e1 = (double)e1f, e2 = (double)e2f, d = (double)dj;
+        const double c1 = power == 2 ? e1 * e1 : e1, c2 = power == 2 ? e2 * e2 : e2, c = power == 2 ? d * d : d;
+        all[r] += fmin(c - c1, 0.0);
+        if (c < c2) atomicAdd(&Bw[(size_t)r * K + cl], fmax(c, c1) - c2);      // rare: x is nearer than j's second medoid
+    };
+    if (vec) {
+        constexpr int U = 4;                                   // steps in flight per lane
+        for (int32_t st = s0; st < s1; st += U) {
+            float4 q[U][PAM_ROWS], e1[U], e2[U];
+            int4 cl[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t j = ((st + u) * 64 + lane) * 4;
+                ok[u] = st + u < s1 && j < n;
+                if (ok[u]) {
+#pragma unroll
+                    for (int r = 0; r < PAM_ROWS; ++r) q[u][r] = *reinterpret_cast<const float4 *>(row[r] + j);
+                    e1[u] = *reinterpret_cast<const float4 *>(d1v + j);
+                    e2[u] = *reinterpret_cast<const float4 *>(d2v + j);
+                    cl[u] = *reinterpret_cast<const int4 *>(nearest + j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int32_t j = ((st + u) * 64 + lane) * 4;
+#pragma unroll
+                for (int r = 0; r < PAM_ROWS; ++r) {
+                    if (!live[r]) continue;                    // block-uniform
+                    relax(r, j, q[u][r].x, e1[u].x, e2[u].x, cl[u].x);
+                    relax(r, j + 1, q[u][r].y, e1[u].y, e2[u].y, cl[u].y);
+                    relax(r, j + 2, q[u][r].z, e1[u].z, e2[u].z, cl[u].z);
+                    relax(r, j + 3, q[u][r].w, e1[u].w, e2[u].w, cl[u].w);
+                }
+            }
         }
+    } else {
+        for (int32_t st = s0; st < s1; ++st)
+            for (int t = 0; t < 4; ++t) {
+                const int32_t j = (st * 4 + t) * 64 + lane;
+                if (j >= n) continue;
+#pragma unroll
+                for (int r = 0; r < PAM_ROWS; ++r)
+                    if (live[r]) relax(r, j, row[r][j], d1v[j], d2v[j], nearest[j]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < PAM_ROWS; ++r) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) all[r] += __shfl_xor(all[r], off, 64);
+        if (lane == 0) s_all[wave][r] = all[r];
     }
     __syncthreads();
     if (PER_WAVE)
-        for (int i = threadIdx.x; i < K; i += 256) {          // waves in order
-            sh[i] = ((sh[i] + sh[2 * K + i]) + sh[4 * K + i]) + sh[6 * K + i];
-            sh[K + i] = ((sh[K + i] + sh[3 * K + i]) + sh[5 * K + i]) + sh[7 * K + i];
-        }
+        for (int i = threadIdx.x; i < PAM_ROWS * K; i += 256)  // waves in order
+            sh[i] = ((sh[i] + sh[(size_t)PAM_ROWS * K + i]) + sh[(size_t)2 * PAM_ROWS * K + i]) + sh[(size_t)3 * PAM_ROWS * K + i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double all = 0.0;
-        for (int32_t i = 0; i < K; ++i) all += sh[i];          // medoid order
+    if (threadIdx.x < PAM_ROWS && x0 + threadIdx.x < n) {
+        const int r = threadIdx.x;
         double best = __longlong_as_double(0x7ff0000000000000LL);
         int32_t arg = 0;
-        for (int32_t i = 0; i < K; ++i) {
-            const double dtd = all + sh[K + i];
-            if (dtd < best) { best = dtd; arg = i; }           // strict: the first medoid wins ties
+        if (live[r]) {
+            const double shared_term = ((s_all[0][r] + s_all[1][r]) + s_all[2][r]) + s_all[3][r];
+            for (int32_t i = 0; i < K; ++i) {
+                const double dtd = shared_term + (base[i] + sh[(size_t)r * K + i]);
+                if (dtd < best) { best = dtd; arg = i; }       // strict: the first medoid wins ties
+            }
         }
-        best_delta[x] = best;
-        best_medoid[x] = arg;
+        best_delta[x0 + r] = best;
+        best_medoid[x0 + r] = arg;
     }
 }
 
 }  // namespace
 
-extern "C" int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const double *c1, const double *c2,
-                                   const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power, double *best_delta_out,
-                                   int32_t *best_medoid_out, void *stream_) {
+extern "C" int geo_pam_swap_deltas(const float *D, int64_t ld, const int32_t *nearest, const float *d1, const float *d2,
+                                   const double *base, const uint8_t *is_medoid, int32_t n, int32_t K, int32_t power,
+                                   double *best_delta_out, int32_t *best_medoid_out, void *stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    GEO_REQUIRE(D && nearest && c1 && c2 && is_medoid && best_delta_out && best_medoid_out, "geo_pam_swap_deltas: null pointer");
-    GEO_REQUIRE(n > 0 && K > 0 && K <= 3584 && ld >= n && (power == 1 || power == 2), "geo_pam_swap_deltas: bad n=%d K=%d ld=%lld power=%d",
+    GEO_REQUIRE(D && nearest && d1 && d2 && base && is_medoid && best_delta_out && best_medoid_out, "geo_pam_swap_deltas: null pointer");
+    GEO_REQUIRE(n > 0 && K > 1 && K <= 3584 && ld >= n && (power == 1 || power == 2), "geo_pam_swap_deltas: bad n=%d K=%d ld=%lld power=%d",
                 n, K, (long long)ld, power);
+    const unsigned grid = (unsigned)((n + PAM_ROWS - 1) / PAM_ROWS);
     if (K <= 896)            // 8 K doubles of LDS per workgroup (<= 56 KB): accumulators per wave, combined in wave order
-        pam_swap_kernel<true><<<(unsigned)n, 256, 8 * (size_t)K * sizeof(double), stream>>>(D, ld, nearest, c1, c2, is_medoid, n, K, power,
-                                                                                          best_delta_out, best_medoid_out);
-    else                     // one pair of accumulators for the workgroup (sums then depend on the waves' interleaving: ~1e-16 relative)
-        pam_swap_kernel<false><<<(unsigned)n, 256, 2 * (size_t)K * sizeof(double), stream>>>(D, ld, nearest, c1, c2, is_medoid, n, K, power,
+        pam_swap_kernel<true><<<grid, 256, (size_t)4 * PAM_ROWS * K * sizeof(double), stream>>>(D, ld, nearest, d1, d2, base, is_medoid, n, K, power,
+                                                                                              best_delta_out, best_medoid_out);
+    else                     // one set of accumulators for the workgroup (sums then depend on the waves' interleaving: ~1e-16 relative)
+        pam_swap_kernel<false><<<grid, 256, (size_t)PAM_ROWS * K * sizeof(double), stream>>>(D, ld, nearest, d1, d2, base, is_medoid, n, K, power,
                                                                                            best_delta_out, best_medoid_out);
     GEO_LAUNCH_CHECK();
     return GEO_OK;

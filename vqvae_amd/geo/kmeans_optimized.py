@@ -422,21 +422,30 @@ def pam_swap_pass_device(D: torch.Tensor, medoids: torch.Tensor, power: int = 2)
     dmin, near = assign_from_rows_device(D, medoids)                 # nearest medoid, first on ties
     near = near.to(torch.int64)
     c1 = dmin.double() ** power
-    if K > 1:
-        rows = D[med].double() ** power                              # K x n
-        rows.scatter_(0, near[None, :], float("inf"))
-        c2 = rows.min(dim=0).values
-        del rows
-    else:
-        c2 = torch.full_like(c1, float("inf"))
+    if K == 1:                                                       # nothing to fall back on: the swap replaces the only medoid
+        tot = torch.cat([(D[r0:r0 + 4096].double() ** power).sum(dim=1) for r0 in range(0, n, 4096)])
+        tot[med] = float("inf")
+        delta = tot.min() - c1.sum()
+        x = int(torch.nonzero(tot == tot.min())[0])
+        return float(delta), 0, x, float(c1.sum())
+    rows = D[med]                                                    # K x n float32 (a copy)
+    rows.scatter_(0, near[None, :], float("inf"))
+    d2 = rows.min(dim=0).values
+    del rows
+    # base[i] = sum over the nodes of medoid i of (c2 - c1), members in ascending node order, sequential fp64 sums
+    # (segment sums through the sorted order: deterministic)
+    gain = d2.double() ** power - c1
+    order = torch.argsort(near, stable=True)
+    counts = torch.bincount(near, minlength=K)
+    base = torch.segment_reduce(gain[order], "sum", lengths=counts)
     is_med = torch.zeros(n, dtype=torch.uint8, device=dev)
     is_med[med] = 1
-    near32, c1, c2 = near.to(torch.int32).contiguous(), c1.contiguous(), c2.contiguous()
+    near32, d1, d2 = near.to(torch.int32).contiguous(), dmin.contiguous(), d2.contiguous()
     best = torch.empty(n, dtype=torch.float64, device=dev)
     which = torch.empty(n, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(near32), ptr(c1), ptr(c2), ptr(is_med), n, K, int(power),
-                                           ptr(best), ptr(which), stream_ptr()), "geo_pam_swap_deltas")
+        _lib.check(lib.geo_pam_swap_deltas(ptr(D), D.stride(0), ptr(near32), ptr(d1), ptr(d2), ptr(base.contiguous()), ptr(is_med), n, K,
+                                           int(power), ptr(best), ptr(which), stream_ptr()), "geo_pam_swap_deltas")
     delta = best.min()
     x = int(torch.nonzero(best == delta)[0])                         # lowest candidate among equal changes
     return float(delta), int(which[x]), x, float(c1.sum())
