@@ -480,7 +480,7 @@ def test_long_geodesics_with_wide_weights_take_the_near_far_push_solve(request):
     np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
 
 
-@pytest.mark.parametrize("delta,persistent,order", [(1, 1, 1), (4, 1, 1), (1000000, 1, 1), (4, 0, 1), (1, 0, 0), (8, 0, 0)])
+@pytest.mark.parametrize("delta,persistent,order", [(1, 1, 1), (4, 1, 2), (1000000, 1, 1), (4, 0, 1), (1, 0, 0), (8, 0, 0), (8, 0, 2)])
 def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persistent, order, request):
     """`sssp_push=2` + 16-source batches send EVERY call with more than 16 sources through the push solve, whatever the
     graph: Gaussian clouds and swiss rolls, one binade of weights or eleven, unweighted, a disconnected graph (inf

@@ -1394,10 +1394,57 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         grouped = true;
         return GEO_OK;
     };
+    // (c) along two landmark HOP counts (`sssp_order=2`): the Morton order of (b) needs two smooth coordinates on the graph,
+    //     not exact distances; breadth-first levels from sources[0] and from the source farthest from it (in hops) cost one
+    //     cheap launch per level instead of one full relaxation sweep per hop of an exact solve.
+    auto order_by_hops = [&]() -> int {
+        int32_t *label = reinterpret_cast<int32_t *>(lm_d), *level_of = label + n;
+        std::vector<int32_t> ka(n_sources), kb(n_sources);
+        auto bfs = [&](int32_t seed_pos, std::vector<int32_t> &out) -> int {
+            GEO_HIP_CHECK(hipMemsetAsync(label, 0xff, 2 * (size_t)n * sizeof(int32_t), stream));
+            cell_seed_kernel<<<1, 64, 0, stream>>>(sources + seed_pos, 1, n, label, level_of, nullptr);
+            GEO_LAUNCH_CHECK();
+            int32_t level = 1, hchanged = 1;
+            while (hchanged && level < n + 2) {
+                for (int g = 0; g < 16; ++g, ++level) {
+                    if (g == 15) GEO_HIP_CHECK(hipMemsetAsync(lm_flags, 0, sizeof(int32_t), stream));   // the group's last level decides
+                    cell_grow_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, indices, n, label, level_of, level, lm_flags);
+                }
+                GEO_LAUNCH_CHECK();
+                GEO_HIP_CHECK(hipMemcpyAsync(&hchanged, lm_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+            gather_i32_kernel<<<geo::grid_for(n_sources, 256, 64), 256, 0, stream>>>(level_of, sources, n_sources, reinterpret_cast<int32_t *>(lm_key));
+            GEO_HIP_CHECK(hipMemcpyAsync(out.data(), lm_key, (size_t)n_sources * 4, hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            return GEO_OK;
+        };
+        if (int rc = bfs(0, ka)) return rc;
+        int32_t far = 0, amax = 0;
+        for (int32_t i = 0; i < n_sources; ++i)
+            if (ka[i] > amax) { amax = ka[i]; far = i; }
+        if (int rc = bfs(far, kb)) return rc;
+        int32_t bmax = 0;
+        for (int32_t i = 0; i < n_sources; ++i) bmax = std::max(bmax, kb[i]);
+        std::vector<uint64_t> key(n_sources);
+        for (int32_t i = 0; i < n_sources; ++i) {
+            // sources the landmarks cannot reach (other components: level -1) sort last
+            const uint32_t qa = ka[i] >= 0 && amax > 0 ? (uint32_t)(65535.0 * ka[i] / amax) : 65535u;
+            const uint32_t qb = kb[i] >= 0 && bmax > 0 ? (uint32_t)(65535.0 * kb[i] / bmax) : 65535u;
+            uint64_t m = 0;
+            for (int bit = 15; bit >= 0; --bit) m = (m << 2) | (uint64_t)(((qa >> bit) & 1u) << 1) | ((qb >> bit) & 1u);
+            key[i] = (m << 32) | (uint32_t)i;
+        }
+        std::sort(key.begin(), key.end());
+        for (int32_t i = 0; i < n_sources; ++i) order[i] = (int32_t)(key[i] & 0xffffffffu);
+        grouped = true;
+        return GEO_OK;
+    };
     // (b) along two landmark distances (round 2; `sssp_order=0`, the default): Morton order of (dist from sources[0], dist from the source
     //     farthest from it).  Also yields the eccentricity of sources[0], which tells the 32-bit solve early that it cannot fit.
     auto regroup_sources = [&]() -> int {
-        if (opt.sssp_order != 0 && n_sources <= CELL_ORDER_MAX_SOURCES) return order_by_cells();
+        if (opt.sssp_order == 2) return order_by_hops();
+        if (opt.sssp_order == 1 && n_sources <= CELL_ORDER_MAX_SOURCES) return order_by_cells();
         int32_t lm_sweeps = 0;
         std::vector<float> ka(n_sources), kb(n_sources);
         const int gk = geo::grid_for(n_sources, 256, 64);
