@@ -14,8 +14,10 @@
  *   - no allocation crosses the ABI: the caller owns inputs, outputs and the workspace `ws`
  *     (size from the matching *_workspace_bytes query, any 256-byte aligned device buffer);
  *   - return value: 0 = ok, negative = error (GEO_E_*); geo_last_error() gives the text;
- *   - thread-compatible, not thread-safe: ONE call at a time per process.  geo_last_error's buffer, the options of
- *     geo_set_option, the sweep profile of geo_sssp_last_profile and its HIP events are process-global.
+ *   - concurrency: calls from DIFFERENT host threads may run at the same time provided each uses its own stream, its own
+ *     workspace and its own output buffers (bench.py pipelines two builds that way); geo_last_error's buffer, the sweep
+ *     profile of geo_sssp_last_profile and its HIP events are per host thread.  The options of geo_set_option are
+ *     process-global: change them only while no call is in flight.
  */
 #ifndef GEO_HIP_H
 #define GEO_HIP_H

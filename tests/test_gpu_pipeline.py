@@ -102,3 +102,32 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity_selfcheck"]["batched_assign_equals_fused"] is True
+
+
+def test_pipelined_builds_equal_builds_one_after_the_other():
+    """vqvae_amd/pipeline.py: several independent builds in flight on one GPU (one host thread + HIP stream + workspace per
+    slot) return exactly what the same builds return one after the other -- graph, edge lengths, medoids, codes, QE -- for
+    latent sets of different sizes (so the slots drift apart) and more sets than slots."""
+    from oracle import metric as om
+    from oracle import synthetic as syn
+    from vqvae_amd._device import device
+    from vqvae_amd.scripts.build_codebook import build_codebook_device, build_codebooks_pipelined
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    dev = device()
+    sd = om.make_decoder_state(4, 16, 1, norm_type="batch")
+    dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "batch")
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(dev).train()
+    sizes = [6000, 2500, 9000, 4096, 7000, 3000, 5000]
+    sets = [torch.from_numpy(syn.gauss_latents(n, 16, 100 + i)).to(dev) for i, n in enumerate(sizes)]
+    kw = dict(k=12, sym="union", K=48, init="kpp", seed=42, batch_size=512)
+    import copy
+    ref = [build_codebook_device(z, copy.deepcopy(dec), **kw) for z in sets]
+    got = build_codebooks_pipelined(sets, dec, depth=3, **kw)
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a["W_lcc"].indices.cpu().numpy(), b["W_lcc"].indices.cpu().numpy())
+        np.testing.assert_array_equal(a["edge_lengths"].cpu().numpy(), b["edge_lengths"].cpu().numpy())
+        np.testing.assert_array_equal(a["medoids"], b["medoids"])
+        np.testing.assert_array_equal(a["assign_flat"], b["assign_flat"])
+        assert a["qe"] == b["qe"]

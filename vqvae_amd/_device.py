@@ -32,9 +32,10 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (288 GB of HBM: keep it resident between calls)."""
+    """Grow-only scratch buffer per device and stream (288 GB of HBM: keep it resident between calls)."""
     nbytes = int(nbytes) + 256
-    key = (dev.type, dev.index)
+    # one buffer per (device, stream): builds pipelined on two streams (bench.py) must not share scratch
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         _ws_cache.pop(key, None)

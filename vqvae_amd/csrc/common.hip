@@ -46,7 +46,7 @@ Options &options() {
     return o;
 }
 
-static char g_err[512] = "";
+static thread_local char g_err[512] = "";       // per host thread: concurrent calls (own stream, own workspace) do not mix messages
 
 void set_error(const char *fmt, ...) {
     va_list ap;

@@ -1040,10 +1040,11 @@ __global__ __launch_bounds__(256) void finish_single_kernel(const double *__rest
 }
 
 // device time of the relaxation sweeps of the last geo_sssp_multi call (HIP events on its stream)
-double g_last_sweep_ms = 0.0;
-int32_t g_last_sweep_launches = 0;
-int32_t g_last_layout = 0;             // sources per batch of the last geo_sssp_multi call, +1000 when chunked
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+// (per host thread: two threads may each drive a build on their own stream and workspace)
+thread_local double g_last_sweep_ms = 0.0;
+thread_local int32_t g_last_sweep_launches = 0;
+thread_local int32_t g_last_layout = 0;             // sources per batch of the last geo_sssp_multi call, +1000 when chunked
+thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 // fp64 single-source solve into d[n] (flags: 4 ints); `group` sweeps between convergence checks
 int solve_single(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n, int32_t source,
