@@ -110,7 +110,7 @@ def make_inputs(name, dev):
     return z, dec, dict(n=n, d=d, k=k, K=K, size=size, cout=cout)
 
 
-def hot_path_step(z, dec, cfg, timers, rank, world):
+def hot_path_step(z, dec, cfg, timers, rank, world, group=None):
     """One full pass; returns (result dict, sweep profile)."""
     from vqvae_amd import _lib
     from vqvae_amd.geo.geo_shortest_paths import sssp_multi_device
@@ -118,9 +118,9 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
     from vqvae_amd.parallel import block_range, gather_latents, sharded_assign
     if world > 1:       # latents arrive row-sharded; the kNN corpus is replicated by one all-gather
         lo, hi = block_range(z.shape[0], rank, world)
-        z = gather_latents(z[lo:hi], z.shape[0])
+        z = gather_latents(z[lo:hi], z.shape[0], group)
     res = build_codebook_device(z, dec, k=cfg["k"], sym="union", K=cfg["K"], init="kpp", seed=42, batch_size=512,
-                                timers=timers)
+                                timers=timers, group=group)
     t0 = time.perf_counter()
     G = res["W_lcc"]
     src = torch.from_numpy(res["medoids"].astype(np.int32)).to(z.device)
@@ -138,9 +138,9 @@ def hot_path_step(z, dec, cfg, timers, rank, world):
                           else f"sweep_multi_kernel<{layout}>")
         return dmin_, arg_
 
-    dmin, arg = sharded_assign(len(res["medoids"]), solve)
+    dmin, arg = sharded_assign(len(res["medoids"]), solve, group)
     ms, launches = np.array([prof.get("ms", 0.0)]), np.array([prof.get("launches", 0)])
-    res["sharded"]["assign"] = world > 1
+    res["sharded"]["assign"] = world > 1 and group is None
     res["sources_this_rank"] = prof.get("sources", 0)
     res["sweep_kernel"] = prof.get("kernel", "sweep_multi_kernel")
     if timers is not None:
@@ -366,7 +366,8 @@ def launch_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--workload", args.workload, "--pipeline", str(args.pipeline)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--workload", args.workload, "--pipeline", str(args.pipeline)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+          (["--replicas"] if args.replicas else [])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -380,6 +381,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("GEO_BENCH_PIPELINE", "4")),
                     help="independent builds in flight on one GPU, each on its own HIP stream and host thread (1 = one after the other)")
+    ap.add_argument("--replicas", action="store_true", default=os.environ.get("GEO_BENCH_REPLICAS", "0") == "1",
+                    help="N > 1: every GPU builds its own codebooks (weak scaling, no data-path collective) instead of sharding each build")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -436,7 +439,13 @@ def main():
     # build is reported beside it.  Ranks of a multi-GPU run issue collectives in program order: no pipelining there.
     import copy
     import threading
-    depth = max(1, args.pipeline) if world == 1 else 1
+    replicas = world > 1 and args.replicas          # every rank on its own: builds are independent objects
+    shard_world = 1 if replicas else world          # ranks ONE build is sharded over
+    depth = max(1, args.pipeline) if shard_world == 1 else 1
+    solo = None
+    if replicas:                                    # a process group of this rank alone: the sharding helpers then see world 1
+        import torch.distributed as dist
+        solo = [dist.new_group([r]) for r in range(world)][rank]
     slots = [(torch.cuda.Stream(device=dev), copy.deepcopy(dec)) for _ in range(depth)] if depth > 1 else [(torch.cuda.current_stream(dev), dec)]
     timers, prof, res = {}, (0.0, 0), None
     all_same = []
@@ -445,7 +454,7 @@ def main():
     streams = [st for st, _ in slots]
 
     def one_step(i, slot):
-        r, pr = hot_path_step(z, slots[slot][1], cfg, None, rank, world)
+        r, pr = hot_path_step(z, slots[slot][1], cfg, None, rank if not replicas else 0, shard_world, solo)
         ok = bool((r["assign_batched"].cpu().numpy() == r["assign_flat"][r["mask_lcc"]]).all())   # (syncs this stream only)
         return i, float(r["qe"]), pr, ok
 
@@ -456,7 +465,7 @@ def main():
         for sl in range(depth):                                   # every slot warms up its own stream and workspace
             with torch.cuda.stream(slots[sl][0]):
                 for _ in range(args.warmup):
-                    hot_path_step(z, slots[sl][1], cfg, None, rank, world)
+                    hot_path_step(z, slots[sl][1], cfg, None, rank if not replicas else 0, shard_world, solo)
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -470,7 +479,7 @@ def main():
         # one more build, alone and instrumented (NOT part of the timed region): stage times and single-build latency
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        res, prof = hot_path_step(z, dec, cfg, timers, rank, world)
+        res, prof = hot_path_step(z, dec, cfg, timers, rank if not replicas else 0, shard_world, solo)
         torch.cuda.synchronize(dev)
         latency_ms = (time.perf_counter() - t1) * 1e3
     if world > 1:
@@ -504,7 +513,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     stages_ms = {k_: v * 1e3 for k_, v in timers.items()}          # of the one instrumented build after the timed region
     sharded = res.get("sharded", {})
-    if world > 1:
+    if replicas:
+        parallelism = f"{world} independent replicas over {backend} (no data-path collective), {depth} builds in flight each"
+    elif world > 1:
         parts = [name for name, on in (("kNN query rows", sharded.get("knn")), ("JVP chunks", sharded.get("jvp")),
                                        ("assignment sources", sharded.get("assign"))) if on]
         parallelism = (f"{world} ranks over {backend}: " + (" + ".join(parts) + " sharded (all-gather merges)" if parts else "nothing sharded")
@@ -512,9 +523,9 @@ def main():
     else:
         parallelism = "1 gpu"
     out = {
-        "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] / (elapsed / args.steps),
+        "metric": "latents/sec through geodesic kNN+APSP+K-medoids", "value": cfg["n"] * (world if replicas else 1) / (elapsed / args.steps),
         "unit": "latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
         "dtype": "f64-exact(u32 fixed point)" if res["sweep_kernel"] == "sweep_chunk32u_kernel" else "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: N={cfg['n']} latents d={cfg['d']} k={cfg['k']} K={cfg['K']} "
                                f"{cfg['size']}px decoder BN-train batch 512 sym=union init=kpp seed=42",
@@ -538,7 +549,7 @@ def main():
     }
     # compute-bound stages: kNN as 2*N^2*d flop vs the fp64 vector peak, JVP as 3.47 MFLOP/edge vs the
     # f32-MFMA peak; stage wall time (whole stage incl. graph assembly / BN statistics), this rank's share of the work
-    share = 1.0 / world
+    share = 1.0 / shard_world
     if stages_ms.get("knn"):
         fl = 2.0 * cfg["n"] ** 2 * cfg["d"] * share
         out["roofline_knn"] = {"bound": "fp64-valu", "achieved": fl / (stages_ms["knn"] * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
@@ -560,10 +571,10 @@ def main():
     # that does not shard (the k-means++ chain + component labelling are replicated) -- the first scaling line explains itself
     E = res["n_edges"]
     out["comm_bytes_per_step"] = {
-        "latents_all_gather": int(cfg["n"] * cfg["d"] * 4 * (world - 1) / world) if world > 1 else 0,
-        "knn_lists_all_gather": int(cfg["n"] * (cfg["k"] + 1) * 4 * (world - 1) / world) if world > 1 else 0,
-        "edge_lengths_all_gather": int(E * 4 * (world - 1) / world) if world > 1 else 0,
-        "assign_min_argmin_all_gather": int(n * 8 * (world - 1)) if world > 1 else 0}
+        "latents_all_gather": int(cfg["n"] * cfg["d"] * 4 * (shard_world - 1) / shard_world) if shard_world > 1 else 0,
+        "knn_lists_all_gather": int(cfg["n"] * (cfg["k"] + 1) * 4 * (shard_world - 1) / shard_world) if shard_world > 1 else 0,
+        "edge_lengths_all_gather": int(E * 4 * (shard_world - 1) / shard_world) if shard_world > 1 else 0,
+        "assign_min_argmin_all_gather": int(n * 8 * (shard_world - 1)) if shard_world > 1 else 0}
     serial_ms = stages_ms.get("kmedoids", 0.0) + stages_ms.get("lcc", 0.0)
     out["serial_fraction"] = {"ms_not_sharded": serial_ms, "of_single_build": serial_ms / latency_ms if latency_ms > 0 else None,
                               "amdahl_limit_8_gpus_single_build": (latency_ms / (serial_ms + (latency_ms - serial_ms) / 8.0)) if world == 1 and latency_ms > 0 else None}
