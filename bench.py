@@ -477,6 +477,8 @@ def main():
         all_same = [ok for _, _, _, ok in done]
         assert len({q for _, q, _, _ in done}) == 1, "pipelined builds disagree"          # every build returned the same QE
         # one more build, alone and instrumented (NOT part of the timed region): stage times and single-build latency
+        if depth > 1:                                             # this stream's workspace has not been used yet: warm it
+            hot_path_step(z, dec, cfg, None, rank if not replicas else 0, shard_world, solo)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         res, prof = hot_path_step(z, dec, cfg, timers, rank if not replicas else 0, shard_world, solo)

@@ -34,7 +34,7 @@ Options from_environment() {
     for (const OptionName &e : kOptionNames) {
         const char *v = getenv(e.env);
         if (!v) continue;
-        if (e.field == &Options::jvp_mid) o.jvp_mid = v[0] == 'f' ? 1 : (v[0] == 'c' ? 2 : atoi(v));
+        if (e.field == &Options::jvp_mid) o.jvp_mid = v[0] == 'f' ? 1 : (v[0] == 'c' ? 2 : (v[0] == 'a' ? 3 : (v[0] == 's' ? 4 : atoi(v))));
         else o.*(e.field) = atoi(v);
     }
     return o;

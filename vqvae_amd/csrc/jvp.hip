@@ -802,6 +802,313 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     }
 }
 
+// ---- ConvT2 with the weights held in registers ("stationary"; dec_channels[1:] = 128, 64) -------------------------
+// mid_all_kernel re-reads 2 MB of weight fragments from the L2 for every 32-sample tile: a fragment feeds only the 64 rows
+// (32 primal + 32 tangent) of one tile, and those loads sit inside the MFMA stream (-2.9 ms of 16.5 when removed).  Here the
+// roles are turned round: a workgroup keeps the fragments of ONE unit of the weight matrix in registers for the whole
+// launch (96 registers per wave, 196 KB per workgroup) and the tiles stream past it.  Units (two 128 x 128 blocks each):
+//   kind 0  an edge pair  : 2 input pixels -> 2 output pixels (128 columns); waves = 4 column tiles x 2 halves of k
+//   kind 1  a centre pixel: 4 input pixels -> 1 output pixel  ( 64 columns); waves = 2 column tiles x 4 quarters of k
+//   kind 2  the corners   : input pixel p -> corner p only    ( 64 columns each), flushed after every input pixel
+// = 4 + 4 + 1 units, 18 block products per tile (mid_all: 20, the corner chunks are half zeros).  The price is staging:
+// every unit stages the input pixels it needs itself (28 pixel stagings per tile instead of 4), so the two waves of a SIMD
+// run the phases of an input pixel in opposite order -- one stages the next pixel (VALU, LDS writes) while the other
+// multiplies the current one (MFMA, LDS reads) -- and the raw pre-activations are re-read from the L2: workgroup ->
+// (XCD = blockIdx % 8, slot = blockIdx / 8), an XCD walks the tiles of the BatchNorm groups g = x (mod 8) with all nine
+// units (3 workgroups per kind-0 unit, 4 per kind-1/2 unit: these stage four pixels per tile), so that a tile's
+// pre-activations come from HBM once and from that XCD's L2 afterwards.  The partial sums of the k slices meet in LDS.
+constexpr int N_UNITS = 9;
+struct UnitTable { int kind[N_UNITS]; int ipix[N_UNITS][4]; int opix[N_UNITS][4]; };
+struct SlotTable { unsigned char unit[32], rank[32], count[32]; };
+
+// Bs[unit][wave][fragment][lane][8] bf16: fragment = (phase * 3 + part) * KSL + k step of the wave's slice
+__global__ __launch_bounds__(256) void pack_stat_kernel(const float *__restrict__ w2, int c1, int c2, UnitTable ut,
+                                                       unsigned short *__restrict__ Bs) {
+    const int KS = c1 / 16;
+    const size_t nf_all = (size_t)3 * KS;                          // fragments per wave: phases x 3 parts x k steps of its slice
+    const size_t total = (size_t)N_UNITS * 8 * nf_all * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int f = (int)((i >> 9) % nf_all), w = (int)((i / (512 * nf_all)) % 8), u = (int)(i / (512 * nf_all * 8));
+        const int kind = ut.kind[u];
+        const int nph = kind == 0 ? 2 : 4, ksl_n = KS / nph;
+        const int ct = kind == 0 ? (w & 3) : (w & 1), sl = kind == 0 ? (w >> 2) : (w >> 1);
+        const int ksl = f % ksl_n, part = (f / ksl_n) % 3, ph = f / (ksl_n * 3);
+        const int k = (sl * ksl_n + ksl) * 16 + (lane >> 5) * 8 + j;
+        const int colu = ct * 32 + (lane & 31);
+        const int co = colu % c2;
+        const int op = kind == 0 ? ut.opix[u][colu / c2] : (kind == 1 ? ut.opix[u][0] : ut.opix[u][ph]);
+        const int ip = ut.ipix[u][ph];
+        const int ky = (op >> 2) + 1 - 2 * (ip >> 1), kx = (op & 3) + 1 - 2 * (ip & 1);
+        float v = 0.0f;
+        if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = w2[(((size_t)k * c2 + co) * 4 + ky) * 4 + kx];
+        unsigned short p[3];
+        split3(v, p[0], p[1], p[2]);
+        Bs[i] = p[part];
+    }
+}
+
+#ifdef GEO_STAT_PROF
+__device__ unsigned long long g_stat_prof[256 * 8 * 8];
+#define GEO_PT(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define GEO_PT(v)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)): in a persistent kernel that drains the epilogue's stores and the prefetched
+// pre-activations at every phase.  Nothing here communicates through global memory inside a launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+extern __shared__ __attribute__((aligned(16))) unsigned char stat_lds[];   // A3 (double buffered) | R
+
+template <int C1, int KIND>
+__device__ __attribute__((noinline)) void mid_stat_body(const float *__restrict__ pre1_, const float *__restrict__ tpre1_,
+                                              const NormConst *__restrict__ consts1_, int consts_per_group, int tpg,
+                                              int n_groups, int4 ipx, int4 opx, int unit, int x, int rank, int count,
+                                              const unsigned short *__restrict__ Bs_, const float *__restrict__ b2_,
+                                              float *__restrict__ pre2_, float *__restrict__ tpre2_,
+                                              double *__restrict__ partial2_, int want_stats, int64_t e_base,
+                                              int64_t n_edges, int batch) {
+    static_assert(C1 == 128, "one lane stages a channel pair: 64 lanes x 2");
+    // (a function that is not inlined sees generic pointers: say that these are global memory, or every access is a flat_
+    //  instruction that also counts against the LDS counter)
+    const GLOBAL_AS float *pre1 = (const GLOBAL_AS float *)pre1_, *tpre1 = (const GLOBAL_AS float *)tpre1_;
+    const GLOBAL_AS NormConst *consts1 = (const GLOBAL_AS NormConst *)consts1_;
+    const GLOBAL_AS unsigned short *Bs = (const GLOBAL_AS unsigned short *)Bs_;
+    const GLOBAL_AS float *b2 = (const GLOBAL_AS float *)b2_;
+    GLOBAL_AS float *pre2 = (GLOBAL_AS float *)pre2_, *tpre2 = (GLOBAL_AS float *)tpre2_;
+    GLOBAL_AS double *partial2 = (GLOBAL_AS double *)partial2_;
+    constexpr int LDK = C1 + 8, KS = C1 / 16;
+    unsigned short *A3 = reinterpret_cast<unsigned short *>(stat_lds);
+    float *R = reinterpret_cast<float *>(stat_lds + (size_t)2 * 3 * 2 * TS * LDK * 2);
+    constexpr int NPH = KIND == 0 ? 2 : 4, NSL = NPH, KSL = KS / NSL;
+    constexpr int c2 = 64, n1 = 4 * C1, n2 = 16 * c2;
+    const int ipix[4] = {ipx.x, ipx.y, ipx.z, ipx.w}, opix[4] = {opx.x, opx.y, opx.z, opx.w};   // (indexed by constants only)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ct = KIND == 0 ? (w & 3) : (w & 1), sl = KIND == 0 ? (w >> 2) : (w >> 1);
+    const bool m_first = ((w >> 2) & 1) != 0;                  // waves w and w ^ 4 share a SIMD and take opposite orders
+    const int r = lane & 31, h = lane >> 5;
+
+    bf16x8 b[NPH][3][KSL];
+    {
+        const GLOBAL_AS unsigned short *bp = Bs + ((size_t)(unit * 8 + w) * (NPH * 3 * KSL)) * 512 + (size_t)lane * 8;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int ksl = 0; ksl < KSL; ++ksl)
+                    b[ph][part][ksl] = *reinterpret_cast<const GLOBAL_AS bf16x8 *>(bp + (size_t)((ph * 3 + part) * KSL + ksl) * 512);
+    }
+    auto a3 = [&](int buf, int part, int strm, int row, int k) -> unsigned short * {
+        return A3 + ((size_t)(((buf * 3 + part) * 2 + strm) * TS + row)) * LDK + k;
+    };
+    auto tile_of = [&](int j, int *tile) -> bool {             // j-th tile of this XCD's groups g = x (mod 8)
+        const int g = (j / tpg) * 8 + x;
+        if (g >= n_groups) return false;
+        *tile = g * tpg + j % tpg;
+        return true;
+    };
+    int j = rank, tile = 0, ntile = 0;
+    if (!tile_of(j, &tile)) return;
+    bool has_next = tile_of(j + count, &ntile);
+
+    // staging: lane -> channels (2 lane, 2 lane + 1), wave -> samples 4 w .. 4 w + 3; the two channels' constants stay in
+    // registers for a tile (no LDS look-ups), the packed pairs go out as conflict-free 4-byte stores
+    const int k0 = 2 * lane, s0 = 4 * w;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 rawp[4], rawt[4];
+    NormConst kA, kB, nA, nB;                                  // this tile's constants; the next tile's (fetched a phase ahead)
+    auto fetch_raw = [&](size_t slot0, int ip) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rawp[i] = *reinterpret_cast<const GLOBAL_AS f32x2 *>(pre1 + (slot0 + s0 + i) * n1 + (size_t)ip * C1 + k0);
+            rawt[i] = *reinterpret_cast<const GLOBAL_AS f32x2 *>(tpre1 + (slot0 + s0 + i) * n1 + (size_t)ip * C1 + k0);
+        }
+    };
+    auto load_consts = [&](int t, NormConst *qa, NormConst *qb) {
+        const GLOBAL_AS float *kp = reinterpret_cast<const GLOBAL_AS float *>(consts1 + (size_t)(consts_per_group ? t / tpg : 0) * C1 + k0);
+        qa->mu = kp[0]; qa->sc = kp[1]; qa->beta = kp[2]; qa->mt = kp[3]; qa->c5 = kp[4];
+        qb->mu = kp[5]; qb->sc = kp[6]; qb->beta = kp[7]; qb->mt = kp[8]; qb->c5 = kp[9];
+    };
+    auto stage = [&](int buf, const NormConst &kA, const NormConst &kB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a0, t0, a1, t1;
+            norm_relu(kA, rawp[i].x, rawt[i].x, &a0, &t0);
+            norm_relu(kB, rawp[i].y, rawt[i].y, &a1, &t1);
+            unsigned short pa0[3], pa1[3], pt0[3], pt1[3];
+            split3(a0, pa0[0], pa0[1], pa0[2]);
+            split3(a1, pa1[0], pa1[1], pa1[2]);
+            split3(t0, pt0[0], pt0[1], pt0[2]);
+            split3(t1, pt1[0], pt1[1], pt1[2]);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                *reinterpret_cast<unsigned *>(a3(buf, part, 0, s0 + i, k0)) = (unsigned)pa0[part] | ((unsigned)pa1[part] << 16);
+                *reinterpret_cast<unsigned *>(a3(buf, part, 1, s0 + i, k0)) = (unsigned)pt0[part] | ((unsigned)pt1[part] << 16);
+            }
+        }
+    };
+
+    // epilogue constants of the lane's column
+    const int colu = ct * 32 + r, co = colu & (c2 - 1);
+    const float bias = b2[co];
+
+    load_consts(tile, &kA, &kB);
+    nA = kA; nB = kB;
+    fetch_raw((size_t)tile * TS, ipix[0]);
+    stage(0, kA, kB);
+    fetch_raw((size_t)tile * TS, ipix[1]);
+    lds_barrier();
+
+    f32x16 accp, acct;
+#ifdef GEO_STAT_PROF
+    unsigned long long pS = 0, pM = 0, pB = 0, pE = 0, pN = 0;
+    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (;;) {
+        // (past the last tile the pipeline keeps running on this tile's addresses: no branches around the loads and stores
+        //  of a phase, the staged block is simply never multiplied)
+        if (!has_next) ntile = tile;
+        const size_t slot0 = (size_t)tile * TS, nslot0 = (size_t)ntile * TS;
+        if (KIND != 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
+        }
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            const int buf = ph & 1;                            // (NPH is even: the parity carries over from tile to tile)
+            const bool last = ph == NPH - 1;
+            const int tp = (ph + 2) % NPH;                     // phase after next: its raw values are fetched now
+            const size_t pslot0 = ph + 2 >= NPH ? nslot0 : slot0;
+            if (KIND == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
+            }
+            GEO_PT(t0);
+            if (!m_first) {
+                if (last) stage(buf ^ 1, nA, nB); else stage(buf ^ 1, kA, kB);     // next: the next tile's first pixel / this tile's next
+                fetch_raw(pslot0, ipix[tp]);
+                if (ph == NPH - 2) load_consts(ntile, &nA, &nB);
+            }
+            GEO_PT(t1);
+#pragma unroll
+            for (int ksl = 0; ksl < KSL; ++ksl) {
+                const int ks = sl * KSL + ksl;
+                bf16x8 ap[3], at[3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    ap[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 0, r, ks * 16 + h * 8));
+                    at[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 1, r, ks * 16 + h * 8));
+                }
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[ph][0][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[ph][0][ksl], acct, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][2][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][2][ksl], acct, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][1][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][1][ksl], acct, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][0][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][0][ksl], acct, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][1][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][1][ksl], acct, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][0][ksl], accp, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][0][ksl], acct, 0, 0, 0);
+            }
+            GEO_PT(t2);
+            if (m_first) {
+                if (last) stage(buf ^ 1, nA, nB); else stage(buf ^ 1, kA, kB);
+                fetch_raw(pslot0, ipix[tp]);
+                if (ph == NPH - 2) load_consts(ntile, &nA, &nB);
+            }
+            GEO_PT(t3);
+            const bool flush = KIND == 2 || last;
+            if (flush && sl > 0) {                             // partial sums of the k slices > 0 -> LDS
+                float *rp = R + (size_t)((KIND == 0 ? ct : ct * 3 + sl - 1) * 32) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { rp[q * 64] = accp[q]; rp[(16 + q) * 64] = acct[q]; }
+            }
+            lds_barrier();
+            GEO_PT(t4);
+            if (flush) {
+                if (sl == 0) {
+#pragma unroll
+                    for (int s2 = 0; s2 < NSL - 1; ++s2) {
+                        const float *rp = R + (size_t)((KIND == 0 ? ct : ct * 3 + s2) * 32) * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { accp[q] += rp[q * 64]; acct[q] += rp[(16 + q) * 64]; }
+                    }
+                }
+                if (KIND == 2) lds_barrier();                  // the corners flush every phase: R is rewritten one phase later
+                if (sl == 0) {
+                    const int op = KIND == 0 ? ((colu >> 6) ? opix[1] : opix[0]) : (KIND == 1 ? opix[0] : opix[ph]);
+                    // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no load)
+                    const int g = tile / tpg;
+                    int64_t cnt = n_edges - (e_base + (int64_t)(g >> 1) * batch);
+                    if (cnt > batch) cnt = batch;
+                    const int n_valid = (int)cnt - (tile - g * tpg) * TS;
+                    double sx = 0, sxx = 0, st_ = 0, sxt = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                        const float xv = accp[q] + bias, tv = acct[q];
+                        pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = xv;
+                        tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = tv;
+                        if (row < n_valid) { sx += xv; sxx += (double)xv * xv; st_ += tv; sxt += (double)xv * tv; }
+                    }
+                    if (want_stats) {
+                        sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+                        st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+                        if (lane < 32) {
+                            GLOBAL_AS double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
+                            p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
+                        }
+                    }
+                }
+            }
+#ifdef GEO_STAT_PROF
+            { GEO_PT(t5); pS += (t1 - t0) + (t3 - t2); pM += t2 - t1; pB += t4 - t3; pE += t5 - t4; pN += 1; }
+#endif
+        }
+        if (!has_next) break;
+        tile = ntile;
+        j += count;
+        has_next = tile_of(j + count, &ntile);
+        kA = nA; kB = nB;
+    }
+#ifdef GEO_STAT_PROF
+    if (lane == 0) {
+        unsigned long long *o = g_stat_prof + ((size_t)blockIdx.x * 8 + w) * 8;
+        o[0] = pS; o[1] = pM; o[2] = pB; o[3] = pE; o[4] = pN; o[5] = __builtin_amdgcn_s_memtime() - pc0; o[6] = KIND;
+        o[7] = __builtin_amdgcn_s_memrealtime() - pr0;
+    }
+#endif
+}
+
+template <int C1>
+__global__ __launch_bounds__(512, 2) void mid_stat_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                                         const NormConst *__restrict__ consts1, int consts_per_group,
+                                                         int tiles_per_group, int n_groups, UnitTable ut, SlotTable st,
+                                                         const unsigned short *__restrict__ Bs,
+                                                         const float *__restrict__ b2, float *__restrict__ pre2,
+                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
+                                                         int want_stats, int64_t e_base, int64_t n_edges, int batch) {
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+    if (s >= 32) return;
+    const int unit = st.unit[s], rank = st.rank[s], count = st.count[s];
+    const int kind = ut.kind[unit];
+    const int4 ipx = make_int4(ut.ipix[unit][0], ut.ipix[unit][1], ut.ipix[unit][2], ut.ipix[unit][3]);
+    const int4 opx = make_int4(ut.opix[unit][0], ut.opix[unit][1], ut.opix[unit][2], ut.opix[unit][3]);
+#define GEO_STAT_BODY(KINDV)                                                                                       \
+    mid_stat_body<C1, KINDV>(pre1, tpre1, consts1, consts_per_group, tiles_per_group, n_groups, ipx, opx, unit, x, rank, \
+                             count, Bs, b2, pre2, tpre2, partial2, want_stats, e_base, n_edges, batch)
+    if (kind == 0) GEO_STAT_BODY(0);
+    else if (kind == 1) GEO_STAT_BODY(1);
+    else GEO_STAT_BODY(2);
+#undef GEO_STAT_BODY
+}
+
 __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
                                                         int64_t n_slots, int32_t *__restrict__ slot_valid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1092,6 +1399,36 @@ void make_chunks(const Shape &s, ChunkTable *t) {
     }
 }
 
+// Units of the weight-stationary ConvT2 kernel (4x4 output pixels from 2x2 input pixels, k4 s2 p1): an output pixel is
+// fed by the input pixels (iy, ix) with 0 <= oy + 1 - 2 iy < 4 and the same in x: corners by one, edge pixels by two (the
+// two edge pixels of a side share them), the four centre pixels by all four.
+void make_units(UnitTable *t, SlotTable *st) {
+    int u = 0;
+    static const int edge[4][2][2] = {{{0, 1}, {0, 2}}, {{3, 1}, {3, 2}}, {{1, 0}, {2, 0}}, {{1, 3}, {2, 3}}};
+    for (int e = 0; e < 4; ++e, ++u) {
+        t->kind[u] = 0;
+        int n = 0;
+        for (int ip = 0; ip < 4; ++ip) {
+            const int ky = edge[e][0][0] + 1 - 2 * (ip >> 1), kx = edge[e][0][1] + 1 - 2 * (ip & 1);
+            if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) t->ipix[u][n++] = ip;
+        }
+        for (int i = n; i < 4; ++i) t->ipix[u][i] = 0;
+        for (int lo = 0; lo < 4; ++lo) t->opix[u][lo] = edge[e][lo & 1][0] * 4 + edge[e][lo & 1][1];
+    }
+    for (int c = 0; c < 4; ++c, ++u) {
+        t->kind[u] = 1;
+        for (int ip = 0; ip < 4; ++ip) { t->ipix[u][ip] = ip; t->opix[u][ip] = (1 + (c >> 1)) * 4 + 1 + (c & 1); }
+    }
+    t->kind[u] = 2;
+    for (int ip = 0; ip < 4; ++ip) { t->ipix[u][ip] = ip; t->opix[u][ip] = 12 * (ip >> 1) + 3 * (ip & 1); }
+    // 32 workgroup slots per XCD: three per edge unit, four per centre / corner unit (those stage four pixels per tile)
+    int cnt[N_UNITS], s = 0;
+    for (int i = 0; i < N_UNITS; ++i) cnt[i] = t->kind[i] == 0 ? 3 : 4;
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < N_UNITS; ++i)
+            if (r < cnt[i] && s < 32) { st->unit[s] = (unsigned char)i; st->rank[s] = (unsigned char)r; st->count[s] = (unsigned char)cnt[i]; ++s; }
+}
+
 struct Plan {
     Shape sh;
     int batch, tiles_per_group, slots_per_group;
@@ -1117,6 +1454,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += geo::align_up((size_t)s.d * s.n1 * 4) + geo::align_up((size_t)s.n1 * 4);          // M01, b01
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 2 * 3);               // B3 (bf16 x 3)
+    b += geo::align_up((size_t)N_UNITS * 8 * 3 * (s.c1 / 16 + 1) * 512 * 2);                // Bs (register-resident units)
     b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
     b += geo::align_up((size_t)16 * s.c2 * 192 * 3 * 2);                                    // W3b (bf16 x 3)
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
@@ -1157,6 +1495,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     float *b01 = ar.take<float>((size_t)s.n1);
     float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
     unsigned short *B3 = ar.take<unsigned short>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 3);
+    unsigned short *Bs = ar.take<unsigned short>((size_t)N_UNITS * 8 * 3 * (s.c1 / 16 + 1) * 512);
     float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
     unsigned short *W3b = ar.take<unsigned short>((size_t)16 * s.c2 * 192 * 3);
     float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
@@ -1197,6 +1536,19 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     if (mid_split) {
         pack_mid_bf16_kernel<<<geo::grid_for((int64_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC, 256), 256, 0, stream>>>(
             B2p, s.c1, s.n_chunks, B3);
+        GEO_LAUNCH_CHECK();
+    }
+    // weight-stationary ConvT2 (the shipped decoder widths), experimental: GEO_JVP_MID=s; default = the tile-resident mid_all_kernel
+    const bool mid_stat = mid_split && mid_opt == 4 && dc->norm != 2 && s.c1 == 128 && s.c2 == 64 && s.n_chunks == 8 && s.opix_per_chunk == 2;
+    UnitTable units;
+    SlotTable slots_tab;
+    const size_t stat_lds_bytes = (size_t)2 * 3 * 2 * TS * (128 + 8) * 2 + (size_t)6 * 32 * 64 * 4;
+    if (mid_stat) {
+        GEO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_stat_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stat_lds_bytes));
+        make_units(&units, &slots_tab);
+        pack_stat_kernel<<<geo::grid_for((int64_t)N_UNITS * 8 * 3 * (s.c1 / 16) * 512, 256), 256, 0, stream>>>(
+            dc->w2, s.c1, s.c2, units, Bs);
         GEO_LAUNCH_CHECK();
     }
 
@@ -1266,8 +1618,12 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
                                                     s.opix_per_chunk, s.c2, B3, dc->b2, pre2, tpre2, part2,        \
                                                     batch_stats ? 1 : 0, slot_valid)
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
-                             mid_opt != 2;
-        if (mid_all) {
+                             mid_opt != 2 && !mid_stat;
+        if (mid_stat) {
+            mid_stat_kernel<128><<<256, 512, stat_lds_bytes, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_groups,
+                                                          units, slots_tab, Bs, dc->b2, pre2, tpre2, part2,
+                                                          batch_stats ? 1 : 0, e_base, n_edges, batch);
+        } else if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
                                                                     pl.tiles_per_group, tab, s.c2, B3, dc->b2,      \
@@ -1326,6 +1682,12 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
 }
 
 }  // namespace
+
+#ifdef GEO_STAT_PROF
+extern "C" int geo_debug_stat_prof(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stat_prof), sizeof(unsigned long long) * 256 * 8 * 8);
+}
+#endif
 
 extern "C" size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size) {
     Plan pl;
