@@ -55,11 +55,11 @@ if fs is not None:
     fs(buf)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)
     for kind in (0, 1, 2):
-        for grp, name in ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7")):
+        for grp, name in ((slice(0, 2), "waves 0-1"), (slice(2, 4), "waves 2-3")):
             sel = a[:, grp, :][a[:, grp, 6] == kind]
             if len(sel) == 0:
                 continue
             n = sel[:, 4].sum()
-            print("kind", kind, name, "per phase: stage %.0f products %.0f barrier %.0f epilogue %.0f  (phases per wave %.0f; loop %.0f ticks = %.0f us of the 100 MHz clock -> %.2f GHz)" % (
+            print("kind", kind, name, "per phase: - %.0f products+stage %.0f barrier %.0f epilogue %.0f  (phases per wave %.0f; loop %.0f ticks = %.0f us of the 100 MHz clock -> %.2f GHz)" % (
                 sel[:, 0].sum() / n, sel[:, 1].sum() / n, sel[:, 2].sum() / n, sel[:, 3].sum() / n, n / len(sel),
                 sel[:, 5].mean(), sel[:, 7].mean() / 100.0, sel[:, 5].mean() / (sel[:, 7].mean() * 10.0)))

@@ -527,6 +527,17 @@ __device__ __forceinline__ void split3(float a, unsigned short &p1, unsigned sho
     p3 = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
+// the same split for two values, the parts packed pairwise (low half = first value): 3 byte permutes instead of shifts and ors
+__device__ __forceinline__ void split3_pair(float a0, float a1, unsigned &w1, unsigned &w2, unsigned &w3) {
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    w1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);   // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    w2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(v0 & 0xffff0000u), q1 = r1 - __uint_as_float(v1 & 0xffff0000u);   // exact
+    w3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
 // B3[chunk][blk][part][ks][h][col][8] bf16: lane (col, h) of the 32x32x16 B operand reads 16 contiguous bytes
 __global__ __launch_bounds__(256) void pack_mid_bf16_kernel(const float *__restrict__ B2p, int c1, int n_chunks,
                                                            unsigned short *__restrict__ B3) {
@@ -645,6 +656,11 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)): that drains the prefetched pre-activations of the next input pixel
+// (and, in a persistent kernel, the epilogue's stores) at every phase.  Nothing here communicates through global memory inside a launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- all eight 128-column chunks of a tile in ONE workgroup (dec_channels[2] = 64) ----------------
 // Staging an input pixel's A block (norm1 + ReLU + 3-way split of 32 x C1 primal and tangent values) costs
 // about as much VALU time as the 96 bf16 MFMAs one chunk spends on it.  Here the block is staged once (by
@@ -660,7 +676,12 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                                                         const float *__restrict__ b2, float *__restrict__ pre2,
                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
                                                         int want_stats, const int32_t *__restrict__ slot_valid,
-                                                        const float4 *__restrict__ gs1) {
+                                                        const float4 *__restrict__ gs1, int64_t e_base, int64_t n_edges,
+                                                        int batch) {
+    // BatchNorm / no norm at 128 channels: a lane stages a channel PAIR of 4 samples (constants in registers, the packed
+    // pairs leave as conflict-free 4-byte stores); GroupNorm and the narrower decoders keep (sample, C1/16 channels)
+    constexpr bool PAIR = C1 == 128 && !GN;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int LDK = C1 + 8;
     constexpr int KS = C1 / 16;
     constexpr int NL = 4;                                      // chunks per wave group
@@ -686,11 +707,26 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     // pixel are fetched (HBM) while the MFMAs of the current one run; one barrier per pixel.
     const int ss = threadIdx.x >> 4, k0 = (threadIdx.x & 15) * CPT;
     float rawp[CPT], rawt[CPT];
-    {
+    const int k0p = 2 * lane, s0p = 4 * wave;
+    f32x2 rp[4], rt[4];
+    NormConst kA = {0.f, 0.f, 0.f, 0.f, 0.f}, kB = kA;
+    if (PAIR) {
+        const NormConst *kp = consts1 + (size_t)(consts_per_group ? group : 0) * C1 + k0p;
+        kA = kp[0];
+        kB = kp[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + k0p);
+            rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + k0p);
+        }
+    } else {
         const float *xp = pre1 + (slot0 + ss) * n1 + k0, *xt = tpre1 + (slot0 + ss) * n1 + k0;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
     }
+    const int colw = wq * 32 + (lane & 31);
+    const int lo = colw / c2, co = colw % c2;
+    const float bias = b2[co];
     // GroupNorm (32 groups): the thread's CPT = C1/16 channels span exactly two groups of C1/32 channels
     float4 gg0 = make_float4(0.f, 0.f, 0.f, 0.f), gg1 = gg0;
     if (GN) {
@@ -700,7 +736,29 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     __syncthreads();                                           // kc visible
     for (int ip = 0; ip < 4; ++ip) {
         const int buf = ip & 1;
-        {
+        if (PAIR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a0, t0, a1, t1;
+                norm_relu(kA, rp[i].x, rt[i].x, &a0, &t0);
+                norm_relu(kB, rp[i].y, rt[i].y, &a1, &t1);
+                unsigned wa[3], wt[3];
+                split3_pair(a0, a1, wa[0], wa[1], wa[2]);
+                split3_pair(t0, t1, wt[0], wt[1], wt[2]);
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    *reinterpret_cast<unsigned *>(&A3[buf][part][0][s0p + i][k0p]) = wa[part];
+                    *reinterpret_cast<unsigned *>(&A3[buf][part][1][s0p + i][k0p]) = wt[part];
+                }
+            }
+            if (ip < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)(ip + 1) * C1 + k0p);
+                    rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)(ip + 1) * C1 + k0p);
+                }
+            }
+        } else {
             unsigned short pp[3][CPT], pt[3][CPT];
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
@@ -717,14 +775,14 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                     A3[buf][part][0][ss][k0 + k] = pp[part][k];
                     A3[buf][part][1][ss][k0 + k] = pt[part][k];
                 }
-        }
-        if (ip < 3) {
-            const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
-            const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
+            if (ip < 3) {
+                const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
+                const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
+                for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
+            }
         }
-        __syncthreads();
+        lds_barrier();                                         // (LDS only: the next pixel's loads stay in flight)
 #pragma unroll
         for (int lc = 0; lc < NL; ++lc) {
             const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
@@ -765,9 +823,10 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
         }
     }
 
-    const int colw = wq * 32 + (lane & 31);
-    const int lo = colw / c2, co = colw % c2;
-    const float bias = b2[co];
+    // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no loads in the epilogue)
+    int64_t cnt_g = n_edges - (e_base + (int64_t)(group >> 1) * batch);
+    if (cnt_g > batch) cnt_g = batch;
+    const int n_valid = (int)cnt_g - (tile - group * tiles_per_group) * TS;
     // batch statistics: a lane's column is the same channel co in all four chunks of its wave, so their (and the two row
     // halves') sums are added in registers; the four waves holding channel co (column quarters wq and wq ^ 2 of both wave
     // groups) meet in LDS and are added in wave order: partial2 is [tile][c2][4], the tile's 16 pixels already summed
@@ -783,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
             const float x = accp[lc][q] + bias, t = acct[lc][q];
             pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
             tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
-            if (slot_valid[slot0 + row]) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
+            if (row < n_valid) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
         }
     }
     if (want_stats) {
@@ -821,18 +880,18 @@ constexpr int N_UNITS = 9;
 struct UnitTable { int kind[N_UNITS]; int ipix[N_UNITS][4]; int opix[N_UNITS][4]; };
 struct SlotTable { unsigned char unit[32], rank[32], count[32]; };
 
-// Bs[unit][wave][fragment][lane][8] bf16: fragment = (phase * 3 + part) * KSL + k step of the wave's slice
+// Bs[unit][wave 0..3][fragment][lane][8] bf16: fragment = (phase * 3 + part) * KSL + k step of the wave's slice
 __global__ __launch_bounds__(256) void pack_stat_kernel(const float *__restrict__ w2, int c1, int c2, UnitTable ut,
                                                        unsigned short *__restrict__ Bs) {
     const int KS = c1 / 16;
-    const size_t nf_all = (size_t)3 * KS;                          // fragments per wave: phases x 3 parts x k steps of its slice
-    const size_t total = (size_t)N_UNITS * 8 * nf_all * 512;
+    const size_t nf_all = (size_t)6 * KS;                          // fragments per wave: phases x 3 parts x k steps of its slice
+    const size_t total = (size_t)N_UNITS * 4 * nf_all * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const int f = (int)((i >> 9) % nf_all), w = (int)((i / (512 * nf_all)) % 8), u = (int)(i / (512 * nf_all * 8));
+        const int f = (int)((i >> 9) % nf_all), w = (int)((i / (512 * nf_all)) % 4), u = (int)(i / (512 * nf_all * 4));
         const int kind = ut.kind[u];
-        const int nph = kind == 0 ? 2 : 4, ksl_n = KS / nph;
-        const int ct = kind == 0 ? (w & 3) : (w & 1), sl = kind == 0 ? (w >> 2) : (w >> 1);
+        const int ksl_n = kind == 0 ? KS : KS / 2;
+        const int ct = kind == 0 ? w : (w & 1), sl = kind == 0 ? 0 : (w >> 1);
         const int ksl = f % ksl_n, part = (f / ksl_n) % 3, ph = f / (ksl_n * 3);
         const int k = (sl * ksl_n + ksl) * 16 + (lane >> 5) * 8 + j;
         const int colu = ct * 32 + (lane & 31);
@@ -855,52 +914,43 @@ __device__ unsigned long long g_stat_prof[256 * 8 * 8];
 #define GEO_PT(v)
 #endif
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
-// store of the wave (s_waitcnt vmcnt(0)): in a persistent kernel that drains the epilogue's stores and the prefetched
-// pre-activations at every phase.  Nothing here communicates through global memory inside a launch.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#define GLOBAL_AS __attribute__((address_space(1)))
 extern __shared__ __attribute__((aligned(16))) unsigned char stat_lds[];   // A3 (double buffered) | R
 
+// One wave per SIMD (256 threads, up to 512 registers per lane: 192 of them hold the unit's weight fragments).  A phase =
+// one input pixel: the wave multiplies the staged block of the pixel (LDS buffer ph & 1) and, between the MFMAs of each
+// k step, stages its share of the NEXT pixel (8 of the 32 samples; lane = channel pair) into the other buffer; the raw
+// pre-activations of the pixel after that and of the one after that are on their way from the L2 meanwhile (two register
+// buffers).  kind 0: wave = 32-column tile, all of k; kinds 1 / 2: wave = (column tile, half of k), halves summed in LDS.
 template <int C1, int KIND>
-__device__ __attribute__((noinline)) void mid_stat_body(const float *__restrict__ pre1_, const float *__restrict__ tpre1_,
-                                              const NormConst *__restrict__ consts1_, int consts_per_group, int tpg,
-                                              int n_groups, int4 ipx, int4 opx, int unit, int x, int rank, int count,
-                                              const unsigned short *__restrict__ Bs_, const float *__restrict__ b2_,
-                                              float *__restrict__ pre2_, float *__restrict__ tpre2_,
-                                              double *__restrict__ partial2_, int want_stats, int64_t e_base,
+__device__ __forceinline__ void mid_stat_body(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                              const NormConst *__restrict__ consts1, int consts_per_group, int tpg,
+                                              int n_groups, const UnitTable &ut, int unit, int x, int rank, int count,
+                                              const unsigned short *__restrict__ Bs, const float *__restrict__ b2,
+                                              float *__restrict__ pre2, float *__restrict__ tpre2,
+                                              double *__restrict__ partial2, int want_stats, int64_t e_base,
                                               int64_t n_edges, int batch) {
     static_assert(C1 == 128, "one lane stages a channel pair: 64 lanes x 2");
-    // (a function that is not inlined sees generic pointers: say that these are global memory, or every access is a flat_
-    //  instruction that also counts against the LDS counter)
-    const GLOBAL_AS float *pre1 = (const GLOBAL_AS float *)pre1_, *tpre1 = (const GLOBAL_AS float *)tpre1_;
-    const GLOBAL_AS NormConst *consts1 = (const GLOBAL_AS NormConst *)consts1_;
-    const GLOBAL_AS unsigned short *Bs = (const GLOBAL_AS unsigned short *)Bs_;
-    const GLOBAL_AS float *b2 = (const GLOBAL_AS float *)b2_;
-    GLOBAL_AS float *pre2 = (GLOBAL_AS float *)pre2_, *tpre2 = (GLOBAL_AS float *)tpre2_;
-    GLOBAL_AS double *partial2 = (GLOBAL_AS double *)partial2_;
     constexpr int LDK = C1 + 8, KS = C1 / 16;
+    constexpr int NPH = KIND == 0 ? 2 : 4, NSL = KIND == 0 ? 1 : 2, KSL = KS / NSL;
+    constexpr int SPW = TS / 4, SPS = SPW / KSL;               // samples staged per wave and phase / per k step
+    constexpr int c2 = 64, n1 = 4 * C1, n2 = 16 * c2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     unsigned short *A3 = reinterpret_cast<unsigned short *>(stat_lds);
     float *R = reinterpret_cast<float *>(stat_lds + (size_t)2 * 3 * 2 * TS * LDK * 2);
-    constexpr int NPH = KIND == 0 ? 2 : 4, NSL = NPH, KSL = KS / NSL;
-    constexpr int c2 = 64, n1 = 4 * C1, n2 = 16 * c2;
-    const int ipix[4] = {ipx.x, ipx.y, ipx.z, ipx.w}, opix[4] = {opx.x, opx.y, opx.z, opx.w};   // (indexed by constants only)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ct = KIND == 0 ? (w & 3) : (w & 1), sl = KIND == 0 ? (w >> 2) : (w >> 1);
-    const bool m_first = ((w >> 2) & 1) != 0;                  // waves w and w ^ 4 share a SIMD and take opposite orders
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address parts)
+    const int ct = KIND == 0 ? w : (w & 1), sl = KIND == 0 ? 0 : (w >> 1);
     const int r = lane & 31, h = lane >> 5;
 
     bf16x8 b[NPH][3][KSL];
     {
-        const GLOBAL_AS unsigned short *bp = Bs + ((size_t)(unit * 8 + w) * (NPH * 3 * KSL)) * 512 + (size_t)lane * 8;
+        const unsigned short *bp = Bs + ((size_t)(unit * 4 + w) * (NPH * 3 * KSL)) * 512 + (size_t)lane * 8;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
             for (int part = 0; part < 3; ++part)
 #pragma unroll
                 for (int ksl = 0; ksl < KSL; ++ksl)
-                    b[ph][part][ksl] = *reinterpret_cast<const GLOBAL_AS bf16x8 *>(bp + (size_t)((ph * 3 + part) * KSL + ksl) * 512);
+                    b[ph][part][ksl] = *reinterpret_cast<const bf16x8 *>(bp + (size_t)((ph * 3 + part) * KSL + ksl) * 512);
     }
     auto a3 = [&](int buf, int part, int strm, int row, int k) -> unsigned short * {
         return A3 + ((size_t)(((buf * 3 + part) * 2 + strm) * TS + row)) * LDK + k;
@@ -911,138 +961,180 @@ __device__ __attribute__((noinline)) void mid_stat_body(const float *__restrict_
         *tile = g * tpg + j % tpg;
         return true;
     };
-    int j = rank, tile = 0, ntile = 0;
-    if (!tile_of(j, &tile)) return;
-    bool has_next = tile_of(j + count, &ntile);
+    // this tile and the two after it (the pipeline looks three phases ahead); past the end the last tile is repeated:
+    // its addresses are valid, what is staged from them is never multiplied
+    int j = rank, T0 = 0, T1 = 0, T2 = 0;
+    if (!tile_of(j, &T0)) return;
+    bool has_next = tile_of(j + count, &T1);
+    if (!has_next) T1 = T0;
+    if (!tile_of(j + 2 * count, &T2)) T2 = T1;
 
-    // staging: lane -> channels (2 lane, 2 lane + 1), wave -> samples 4 w .. 4 w + 3; the two channels' constants stay in
-    // registers for a tile (no LDS look-ups), the packed pairs go out as conflict-free 4-byte stores
-    const int k0 = 2 * lane, s0 = 4 * w;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 rawp[4], rawt[4];
-    NormConst kA, kB, nA, nB;                                  // this tile's constants; the next tile's (fetched a phase ahead)
-    auto fetch_raw = [&](size_t slot0, int ip) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rawp[i] = *reinterpret_cast<const GLOBAL_AS f32x2 *>(pre1 + (slot0 + s0 + i) * n1 + (size_t)ip * C1 + k0);
-            rawt[i] = *reinterpret_cast<const GLOBAL_AS f32x2 *>(tpre1 + (slot0 + s0 + i) * n1 + (size_t)ip * C1 + k0);
-        }
-    };
+    const int k0 = 2 * lane, s0 = SPW * w;
+    f32x2 rp[2][SPW], rt[2][SPW];                              // two raw buffers, indexed by phase parity (constants after unrolling)
+    NormConst kA, kB, nA, nB;                                  // constants of the lane's two channels: this tile's, the next tile's
     auto load_consts = [&](int t, NormConst *qa, NormConst *qb) {
-        const GLOBAL_AS float *kp = reinterpret_cast<const GLOBAL_AS float *>(consts1 + (size_t)(consts_per_group ? t / tpg : 0) * C1 + k0);
-        qa->mu = kp[0]; qa->sc = kp[1]; qa->beta = kp[2]; qa->mt = kp[3]; qa->c5 = kp[4];
-        qb->mu = kp[5]; qb->sc = kp[6]; qb->beta = kp[7]; qb->mt = kp[8]; qb->c5 = kp[9];
+        const NormConst *kp = consts1 + (size_t)(consts_per_group ? t / tpg : 0) * C1 + k0;
+        *qa = kp[0];
+        *qb = kp[1];
     };
-    auto stage = [&](int buf, const NormConst &kA, const NormConst &kB) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a0, t0, a1, t1;
-            norm_relu(kA, rawp[i].x, rawt[i].x, &a0, &t0);
-            norm_relu(kB, rawp[i].y, rawt[i].y, &a1, &t1);
-            unsigned short pa0[3], pa1[3], pt0[3], pt1[3];
-            split3(a0, pa0[0], pa0[1], pa0[2]);
-            split3(a1, pa1[0], pa1[1], pa1[2]);
-            split3(t0, pt0[0], pt0[1], pt0[2]);
-            split3(t1, pt1[0], pt1[1], pt1[2]);
-#pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                *reinterpret_cast<unsigned *>(a3(buf, part, 0, s0 + i, k0)) = (unsigned)pa0[part] | ((unsigned)pa1[part] << 16);
-                *reinterpret_cast<unsigned *>(a3(buf, part, 1, s0 + i, k0)) = (unsigned)pt0[part] | ((unsigned)pt1[part] << 16);
-            }
-        }
-    };
+    auto tile_at = [&](int idx) -> int { return idx == 0 ? T0 : (idx == 1 ? T1 : T2); };
 
-    // epilogue constants of the lane's column
     const int colu = ct * 32 + r, co = colu & (c2 - 1);
     const float bias = b2[co];
 
-    load_consts(tile, &kA, &kB);
+#define GEO_FETCH(RB, I, KPH)                                                                                        \
+    {                                                                                                                \
+        const size_t fs_ = (size_t)tile_at((KPH) / NPH) * TS + s0 + (I);                                             \
+        const int fp_ = ut.ipix[unit][(KPH) % NPH];                                                                  \
+        rp[RB][I] = *reinterpret_cast<const f32x2 *>(pre1 + fs_ * n1 + (size_t)fp_ * C1 + k0);                       \
+        rt[RB][I] = *reinterpret_cast<const f32x2 *>(tpre1 + fs_ * n1 + (size_t)fp_ * C1 + k0);                      \
+    }
+#define GEO_STAGE(BUF, RB, I, QA, QB)                                                                                \
+    {                                                                                                                \
+        float a0_, t0_, a1_, t1_;                                                                                    \
+        norm_relu(QA, rp[RB][I].x, rt[RB][I].x, &a0_, &t0_);                                                         \
+        norm_relu(QB, rp[RB][I].y, rt[RB][I].y, &a1_, &t1_);                                                         \
+        unsigned wa_[3], wt_[3];                                                                                     \
+        split3_pair(a0_, a1_, wa_[0], wa_[1], wa_[2]);                                                               \
+        split3_pair(t0_, t1_, wt_[0], wt_[1], wt_[2]);                                                               \
+        _Pragma("unroll") for (int part_ = 0; part_ < 3; ++part_) {                                                  \
+            *reinterpret_cast<unsigned *>(a3(BUF, part_, 0, s0 + (I), k0)) = wa_[part_];                             \
+            *reinterpret_cast<unsigned *>(a3(BUF, part_, 1, s0 + (I), k0)) = wt_[part_];                             \
+        }                                                                                                            \
+    }
+
+    load_consts(T0, &kA, &kB);
     nA = kA; nB = kB;
-    fetch_raw((size_t)tile * TS, ipix[0]);
-    stage(0, kA, kB);
-    fetch_raw((size_t)tile * TS, ipix[1]);
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) GEO_FETCH(0, i, 0)
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) GEO_FETCH(1, i, 1)
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) GEO_STAGE(0, 0, i, kA, kB)
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) GEO_FETCH(0, i, 2)
     lds_barrier();
 
     f32x16 accp, acct;
 #ifdef GEO_STAT_PROF
-    unsigned long long pS = 0, pM = 0, pB = 0, pE = 0, pN = 0;
+    unsigned long long pM = 0, pB = 0, pE = 0, pN = 0;
     const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (;;) {
-        // (past the last tile the pipeline keeps running on this tile's addresses: no branches around the loads and stores
-        //  of a phase, the staged block is simply never multiplied)
-        if (!has_next) ntile = tile;
-        const size_t slot0 = (size_t)tile * TS, nslot0 = (size_t)ntile * TS;
+        const int tile = T0;
+        const size_t slot0 = (size_t)tile * TS;
         if (KIND != 2) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
         }
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int buf = ph & 1;                            // (NPH is even: the parity carries over from tile to tile)
+            const int buf = ph & 1;                            // (NPH is even: phase parity carries over from tile to tile)
             const bool last = ph == NPH - 1;
-            const int tp = (ph + 2) % NPH;                     // phase after next: its raw values are fetched now
-            const size_t pslot0 = ph + 2 >= NPH ? nslot0 : slot0;
             if (KIND == 2) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
             }
             GEO_PT(t0);
-            if (!m_first) {
-                if (last) stage(buf ^ 1, nA, nB); else stage(buf ^ 1, kA, kB);     // next: the next tile's first pixel / this tile's next
-                fetch_raw(pslot0, ipix[tp]);
-                if (ph == NPH - 2) load_consts(ntile, &nA, &nB);
-            }
-            GEO_PT(t1);
-#pragma unroll
-            for (int ksl = 0; ksl < KSL; ++ksl) {
-                const int ks = sl * KSL + ksl;
-                bf16x8 ap[3], at[3];
+            if (ph == NPH - 2) load_consts(T1, &nA, &nB);      // used by the last phase's staging (the next tile's first pixel)
+            // One wave per SIMD has no partner to cover its waits: the instruction stream itself is the schedule.  Per k
+            // step: 12 MFMAs; behind each one a fixed piece of the other work -- one of the six LDS reads of the NEXT step's
+            // A fragments, or a quarter of a sample's staging (normalise / split primal / split tangent / stores and the
+            // refill of its raw registers) -- and a scheduling barrier, so that the compiler keeps the pieces there.
+            const NormConst &qA = last ? nA : kA, &qB = last ? nB : kB;
+            constexpr int RB = 0; (void)RB;
+            bf16x8 ap[3], at[3], apn[3], atn[3];
+            {
+                const int ks0 = sl * KSL;
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    ap[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 0, r, ks * 16 + h * 8));
-                    at[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 1, r, ks * 16 + h * 8));
+                    ap[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 0, r, ks0 * 16 + h * 8));
+                    at[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 1, r, ks0 * 16 + h * 8));
                 }
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[ph][0][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[ph][0][ksl], acct, 0, 0, 0);
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][2][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][2][ksl], acct, 0, 0, 0);
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][1][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][1][ksl], acct, 0, 0, 0);
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][0][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][0][ksl], acct, 0, 0, 0);
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][1][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][1][ksl], acct, 0, 0, 0);
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][0][ksl], accp, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][0][ksl], acct, 0, 0, 0);
             }
-            GEO_PT(t2);
-            if (m_first) {
-                if (last) stage(buf ^ 1, nA, nB); else stage(buf ^ 1, kA, kB);
-                fetch_raw(pslot0, ipix[tp]);
-                if (ph == NPH - 2) load_consts(ntile, &nA, &nB);
-            }
-            GEO_PT(t3);
-            const bool flush = KIND == 2 || last;
-            if (flush && sl > 0) {                             // partial sums of the k slices > 0 -> LDS
-                float *rp = R + (size_t)((KIND == 0 ? ct : ct * 3 + sl - 1) * 32) * 64 + lane;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { rp[q * 64] = accp[q]; rp[(16 + q) * 64] = acct[q]; }
+            for (int ksl = 0; ksl < KSL; ++ksl) {
+                const int ksn = sl * KSL + (ksl + 1 < KSL ? ksl + 1 : ksl);      // (the last step re-reads its own: keeps the stream uniform)
+                const int rb = (ph + 1) & 1;
+                float sa0[SPS], st0[SPS], sa1[SPS], st1[SPS];
+                unsigned wa[SPS][3], wt[SPS][3];
+#define GEO_NEXT_A(PART, STRM)                                                                                      \
+    { if (STRM == 0) apn[PART] = *reinterpret_cast<const bf16x8 *>(a3(buf, PART, 0, r, ksn * 16 + h * 8));          \
+      else atn[PART] = *reinterpret_cast<const bf16x8 *>(a3(buf, PART, 1, r, ksn * 16 + h * 8)); }
+#define GEO_NORM(U)                                                                                                  \
+    { const int i_ = ksl * SPS + (U);                                                                                \
+      norm_relu(qA, rp[rb][i_].x, rt[rb][i_].x, &sa0[U], &st0[U]);                                                   \
+      norm_relu(qB, rp[rb][i_].y, rt[rb][i_].y, &sa1[U], &st1[U]); }
+#define GEO_SPLIT_A(U) split3_pair(sa0[U], sa1[U], wa[U][0], wa[U][1], wa[U][2]);
+#define GEO_SPLIT_T(U) split3_pair(st0[U], st1[U], wt[U][0], wt[U][1], wt[U][2]);
+#define GEO_WRITE(U, STRM)                                                                                           \
+    { const int i_ = ksl * SPS + (U);                                                                                \
+      _Pragma("unroll") for (int part_ = 0; part_ < 3; ++part_)                                                      \
+          *reinterpret_cast<unsigned *>(a3(buf ^ 1, part_, STRM, s0 + i_, k0)) = STRM == 0 ? wa[U][part_] : wt[U][part_]; }
+#define GEO_REFILL(U) { const int i_ = ksl * SPS + (U); GEO_FETCH(rb, i_, ph + 3) }
+#define GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[ph][0][ksl], accp, 0, 0, 0);
+                GEO_NEXT_A(0, 0) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[ph][0][ksl], acct, 0, 0, 0);
+                GEO_NEXT_A(0, 1) GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][2][ksl], accp, 0, 0, 0);
+                GEO_NORM(0) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][2][ksl], acct, 0, 0, 0);
+                GEO_NEXT_A(1, 0) if (SPS > 1) GEO_SPLIT_A(0) GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][1][ksl], accp, 0, 0, 0);
+                GEO_NEXT_A(1, 1) if (SPS > 1) GEO_SPLIT_T(0) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][1][ksl], acct, 0, 0, 0);
+                if (SPS == 1) GEO_SPLIT_A(0) else { GEO_WRITE(0, 0) GEO_WRITE(0, 1) } GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][0][ksl], accp, 0, 0, 0);
+                GEO_NEXT_A(2, 0) if (SPS > 1) GEO_REFILL(0) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][0][ksl], acct, 0, 0, 0);
+                GEO_NEXT_A(2, 1) GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][1][ksl], accp, 0, 0, 0);
+                if (SPS == 1) GEO_SPLIT_T(0) else GEO_NORM(SPS - 1) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][1][ksl], acct, 0, 0, 0);
+                if (SPS == 1) GEO_WRITE(0, 0) else GEO_SPLIT_A(SPS - 1) GEO_SLOT_END
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][0][ksl], accp, 0, 0, 0);
+                if (SPS == 1) GEO_WRITE(0, 1) else GEO_SPLIT_T(SPS - 1) GEO_SLOT_END
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][0][ksl], acct, 0, 0, 0);
+                if (SPS == 1) GEO_REFILL(0) else { GEO_WRITE(SPS - 1, 0) GEO_WRITE(SPS - 1, 1) GEO_REFILL(SPS - 1) } GEO_SLOT_END
+                // the pieces are pure values to the compiler and land wherever it likes: pin the pattern instead -- per slot one
+                // MFMA, then an LDS read (first six slots), a handful of vector instructions, an LDS store / a global load
+#pragma unroll
+                for (int slot = 0; slot < 12; ++slot) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                    if (slot < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, SPS == 1 ? 5 : 9, 0);   // VALU
+                    if (slot >= 6) __builtin_amdgcn_sched_group_barrier(0x200, SPS, 0); // DS write
+                    if (slot >= 10) __builtin_amdgcn_sched_group_barrier(0x020, SPS, 0);// VMEM read
+                }
+#undef GEO_NEXT_A
+#undef GEO_NORM
+#undef GEO_SPLIT_A
+#undef GEO_SPLIT_T
+#undef GEO_WRITE
+#undef GEO_REFILL
+#undef GEO_SLOT_END
+#pragma unroll
+                for (int part = 0; part < 3; ++part) { ap[part] = apn[part]; at[part] = atn[part]; }
+            }
+            GEO_PT(t1);
+            const bool flush = KIND == 2 || last;
+            if (NSL > 1 && flush && sl > 0) {                  // partial sums of the second half of k -> LDS
+                float *rq = R + (size_t)(ct * 32) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { rq[q * 64] = accp[q]; rq[(16 + q) * 64] = acct[q]; }
             }
             lds_barrier();
-            GEO_PT(t4);
+            GEO_PT(t2);
             if (flush) {
-                if (sl == 0) {
+                if (NSL > 1 && sl == 0) {
+                    const float *rq = R + (size_t)(ct * 32) * 64 + lane;
 #pragma unroll
-                    for (int s2 = 0; s2 < NSL - 1; ++s2) {
-                        const float *rp = R + (size_t)((KIND == 0 ? ct : ct * 3 + s2) * 32) * 64 + lane;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) { accp[q] += rp[q * 64]; acct[q] += rp[(16 + q) * 64]; }
-                    }
+                    for (int q = 0; q < 16; ++q) { accp[q] += rq[q * 64]; acct[q] += rq[(16 + q) * 64]; }
                 }
                 if (KIND == 2) lds_barrier();                  // the corners flush every phase: R is rewritten one phase later
                 if (sl == 0) {
-                    const int op = KIND == 0 ? ((colu >> 6) ? opix[1] : opix[0]) : (KIND == 1 ? opix[0] : opix[ph]);
+                    const int op = KIND == 0 ? ut.opix[unit][colu >> 6] : (KIND == 1 ? ut.opix[unit][0] : ut.opix[unit][ph]);
                     // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no load)
                     const int g = tile / tpg;
                     int64_t cnt = n_edges - (e_base + (int64_t)(g >> 1) * batch);
@@ -1061,47 +1153,51 @@ __device__ __attribute__((noinline)) void mid_stat_body(const float *__restrict_
                         sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
                         st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
                         if (lane < 32) {
-                            GLOBAL_AS double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
+                            double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
                             p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
                         }
                     }
                 }
             }
 #ifdef GEO_STAT_PROF
-            { GEO_PT(t5); pS += (t1 - t0) + (t3 - t2); pM += t2 - t1; pB += t4 - t3; pE += t5 - t4; pN += 1; }
+            { GEO_PT(t3); pM += t1 - t0; pB += t2 - t1; pE += t3 - t2; pN += 1; }
 #endif
         }
         if (!has_next) break;
-        tile = ntile;
         j += count;
-        has_next = tile_of(j + count, &ntile);
+        T0 = T1;
+        {
+            int t1_ = 0;
+            has_next = tile_of(j + count, &t1_);
+            T1 = has_next ? t1_ : T0;
+            if (!tile_of(j + 2 * count, &T2)) T2 = T1;
+        }
         kA = nA; kB = nB;
     }
+#undef GEO_FETCH
+#undef GEO_STAGE
 #ifdef GEO_STAT_PROF
     if (lane == 0) {
         unsigned long long *o = g_stat_prof + ((size_t)blockIdx.x * 8 + w) * 8;
-        o[0] = pS; o[1] = pM; o[2] = pB; o[3] = pE; o[4] = pN; o[5] = __builtin_amdgcn_s_memtime() - pc0; o[6] = KIND;
+        o[0] = 0; o[1] = pM; o[2] = pB; o[3] = pE; o[4] = pN; o[5] = __builtin_amdgcn_s_memtime() - pc0; o[6] = KIND;
         o[7] = __builtin_amdgcn_s_memrealtime() - pr0;
     }
 #endif
 }
 
 template <int C1>
-__global__ __launch_bounds__(512, 2) void mid_stat_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
-                                                         const NormConst *__restrict__ consts1, int consts_per_group,
-                                                         int tiles_per_group, int n_groups, UnitTable ut, SlotTable st,
-                                                         const unsigned short *__restrict__ Bs,
-                                                         const float *__restrict__ b2, float *__restrict__ pre2,
-                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
-                                                         int want_stats, int64_t e_base, int64_t n_edges, int batch) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mid_stat_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                     const NormConst *__restrict__ consts1, int consts_per_group, int tiles_per_group, int n_groups,
+                     UnitTable ut, SlotTable st, const unsigned short *__restrict__ Bs, const float *__restrict__ b2,
+                     float *__restrict__ pre2, float *__restrict__ tpre2, double *__restrict__ partial2, int want_stats,
+                     int64_t e_base, int64_t n_edges, int batch) {
     const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
     if (s >= 32) return;
     const int unit = st.unit[s], rank = st.rank[s], count = st.count[s];
     const int kind = ut.kind[unit];
-    const int4 ipx = make_int4(ut.ipix[unit][0], ut.ipix[unit][1], ut.ipix[unit][2], ut.ipix[unit][3]);
-    const int4 opx = make_int4(ut.opix[unit][0], ut.opix[unit][1], ut.opix[unit][2], ut.opix[unit][3]);
 #define GEO_STAT_BODY(KINDV)                                                                                       \
-    mid_stat_body<C1, KINDV>(pre1, tpre1, consts1, consts_per_group, tiles_per_group, n_groups, ipx, opx, unit, x, rank, \
+    mid_stat_body<C1, KINDV>(pre1, tpre1, consts1, consts_per_group, tiles_per_group, n_groups, ut, unit, x, rank,   \
                              count, Bs, b2, pre2, tpre2, partial2, want_stats, e_base, n_edges, batch)
     if (kind == 0) GEO_STAT_BODY(0);
     else if (kind == 1) GEO_STAT_BODY(1);
@@ -1454,7 +1550,7 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += geo::align_up((size_t)s.d * s.n1 * 4) + geo::align_up((size_t)s.n1 * 4);          // M01, b01
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 2 * 3);               // B3 (bf16 x 3)
-    b += geo::align_up((size_t)N_UNITS * 8 * 3 * (s.c1 / 16 + 1) * 512 * 2);                // Bs (register-resident units)
+    b += geo::align_up((size_t)N_UNITS * 4 * 6 * (s.c1 / 16 + 1) * 512 * 2);                // Bs (register-resident units)
     b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
     b += geo::align_up((size_t)16 * s.c2 * 192 * 3 * 2);                                    // W3b (bf16 x 3)
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
@@ -1495,7 +1591,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     float *b01 = ar.take<float>((size_t)s.n1);
     float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
     unsigned short *B3 = ar.take<unsigned short>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 3);
-    unsigned short *Bs = ar.take<unsigned short>((size_t)N_UNITS * 8 * 3 * (s.c1 / 16 + 1) * 512);
+    unsigned short *Bs = ar.take<unsigned short>((size_t)N_UNITS * 4 * 6 * (s.c1 / 16 + 1) * 512);
     float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
     unsigned short *W3b = ar.take<unsigned short>((size_t)16 * s.c2 * 192 * 3);
     float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
@@ -1542,12 +1638,12 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     const bool mid_stat = mid_split && mid_opt == 4 && dc->norm != 2 && s.c1 == 128 && s.c2 == 64 && s.n_chunks == 8 && s.opix_per_chunk == 2;
     UnitTable units;
     SlotTable slots_tab;
-    const size_t stat_lds_bytes = (size_t)2 * 3 * 2 * TS * (128 + 8) * 2 + (size_t)6 * 32 * 64 * 4;
+    const size_t stat_lds_bytes = (size_t)2 * 3 * 2 * TS * (128 + 8) * 2 + (size_t)2 * 32 * 64 * 4;
     if (mid_stat) {
         GEO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_stat_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)stat_lds_bytes));
         make_units(&units, &slots_tab);
-        pack_stat_kernel<<<geo::grid_for((int64_t)N_UNITS * 8 * 3 * (s.c1 / 16) * 512, 256), 256, 0, stream>>>(
+        pack_stat_kernel<<<geo::grid_for((int64_t)N_UNITS * 4 * 6 * (s.c1 / 16) * 512, 256), 256, 0, stream>>>(
             dc->w2, s.c1, s.c2, units, Bs);
         GEO_LAUNCH_CHECK();
     }
@@ -1620,7 +1716,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
                              mid_opt != 2 && !mid_stat;
         if (mid_stat) {
-            mid_stat_kernel<128><<<256, 512, stat_lds_bytes, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_groups,
+            mid_stat_kernel<128><<<256, 256, stat_lds_bytes, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_groups,
                                                           units, slots_tab, Bs, dc->b2, pre2, tpre2, part2,
                                                           batch_stats ? 1 : 0, e_base, n_edges, batch);
         } else if (mid_all) {
@@ -1628,7 +1724,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
                                                                     pl.tiles_per_group, tab, s.c2, B3, dc->b2,      \
                                                                     pre2, tpre2, part2, batch_stats ? 1 : 0,        \
-                                                                    slot_valid, gs1)
+                                                                    slot_valid, gs1, e_base, n_edges, batch)
             if (gs1) {
                 if (s.c1 == 128) GEO_MIDA(128, true);
                 else if (s.c1 == 64) GEO_MIDA(64, true);
