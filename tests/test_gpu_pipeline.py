@@ -104,6 +104,33 @@ def test_bench_prints_one_contract_line():
     assert d["parity_selfcheck"]["batched_assign_equals_fused"] is True
 
 
+def test_bench_two_ranks_with_sharded_builds_in_flight():
+    """`bench.py --gpus 2` on the one-GPU box (two rank processes over gloo sharing the card; RCCL when the box has a GPU per
+    rank): every build sharded over the ranks AND three builds in flight per rank, their collectives issued in ticket order
+    on the one communicator (parallel.CollectiveOrder).  The run must end (no rank parked behind a ticket), every build must
+    return the same QE as the one-rank run, and the line must say what it did."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for gpus in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--gpus", str(gpus), "--steps", "7",
+                              "--warmup", "1", "--pipeline", "3", "--no-cpu-baseline"],
+                             capture_output=True, text=True, timeout=900, cwd=root,
+                             env=dict(os.environ, **({"GEO_BENCH_BACKEND": "gloo"} if torch.cuda.device_count() < gpus else {})))
+        assert out.returncode == 0, out.stderr[-3000:]
+        js = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(js) == 1, out.stdout[-2000:]
+        lines[gpus] = json.loads(js[0])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["pipeline_depth"] == 3
+    assert "ticket order" in two["config"]["parallelism"] and "kNN query rows" in two["config"]["parallelism"]
+    assert two["parity_selfcheck"]["batched_assign_equals_fused"] is True
+    assert two["parity_selfcheck"]["qe"] == one["parity_selfcheck"]["qe"]
+    assert two["config"]["graph"] == one["config"]["graph"]
+
+
 def test_pipelined_builds_equal_builds_one_after_the_other():
     """vqvae_amd/pipeline.py: several independent builds in flight on one GPU (one host thread + HIP stream + workspace per
     slot) return exactly what the same builds return one after the other -- graph, edge lengths, medoids, codes, QE -- for

@@ -16,16 +16,100 @@ What shards and what is exchanged
 
 The functions take the local compute as a callable, so the distributed logic is the same code on the GPU
 (HIP kernels) and in the gloo tests (which plug in the CPU oracle as the compute).
+
+Several sharded builds in flight per rank (`CollectiveOrder`): a communicator executes collectives in the order they are
+issued, and every rank must issue them in the SAME order.  With one host thread per build that order is no longer program
+order, so each collective carries a ticket that all ranks compute alike, and a thread issues its collective only when every
+smaller ticket has been issued or given up.  One communicator, one order: nothing here relies on concurrent communicators.
 """
+import threading
 from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+# collectives of one build, in program order; the last two follow the serial k-means++ chain
+STAGES = ("latents", "knn_idx", "knn_d2", "edge_lengths", "bn_fold", "assign_d", "assign_a")
+LATE = {"assign_d", "assign_a"}
+
+
+class CollectiveOrder:
+    """Issue order of the collectives of builds 0 .. n_builds-1 when `depth` of them are in flight on every rank.
+
+    Ticket of (build i, stage s) = (i + lag(s), index of s, i) with lag = depth - 1 for the stages behind the chain and 0 for
+    the others: the early collectives of build i + depth - 1 (which starts when build i - 1 ends) come before the final
+    ones of build i, so a build's kNN / JVP exchange never queues behind an older build's chain.  A build issues its stages
+    in program order and may skip some (e.g. the fp64 kNN distances); a stage counts as given up once its build has moved
+    past it or finished.  Deadlock-free: a waiting ticket only waits for builds that are already in flight (run_pipelined
+    hands out builds in order, `depth` at a time) and whose progress does not depend on it."""
+
+    def __init__(self, n_builds: int, depth: int):
+        self.n, self.lag = int(n_builds), max(0, int(depth) - 1)
+        self.done = [0] * self.n                   # per build: number of leading stages issued or given up
+        self.cv = threading.Condition()
+        self.aborted: Optional[BaseException] = None
+
+    def _ticket(self, build: int, stage_idx: int):
+        return (build + (self.lag if STAGES[stage_idx] in LATE else 0), stage_idx, build)
+
+    def _clear(self, ticket) -> bool:
+        for b in range(self.n):                    # (a handful of builds are in flight: a linear scan is fine)
+            d = self.done[b]
+            if d < len(STAGES) and self._ticket(b, d) < ticket:
+                return False                       # build b has not reached / passed a stage that must come first
+        return True
+
+    def issue(self, build: int, stage: str, fn: Callable):
+        """Runs fn() (which issues ONE collective) when the ticket comes up."""
+        si = STAGES.index(stage)
+        with self.cv:
+            assert self.done[build] <= si, (build, stage, self.done[build])
+            self.done[build] = si                  # earlier stages of this build are given up
+            self.cv.notify_all()
+            me = self._ticket(build, si)
+            while not self._clear(me):
+                if self.aborted is not None:
+                    raise RuntimeError("another build of the pipeline failed") from self.aborted
+                self.cv.wait(timeout=1.0)
+            try:
+                return fn()                        # issued under the lock: the order of issue IS the ticket order
+            finally:
+                self.done[build] = si + 1
+                self.cv.notify_all()
+
+    def finish(self, build: int) -> None:
+        with self.cv:
+            self.done[build] = len(STAGES)
+            self.cv.notify_all()
+
+    def abort(self, error: BaseException) -> None:
+        """A build failed: wake the waiting ones (they raise) instead of leaving them parked behind a ticket that never comes."""
+        with self.cv:
+            self.aborted = error
+            self.cv.notify_all()
+
+
+class OrderedGroup:
+    """What a build passes as `group` when several sharded builds are in flight: the process group + its place in the order."""
+
+    def __init__(self, order: CollectiveOrder, build: int, pg=None):
+        self.order, self.build, self.pg = order, build, pg
+
+
+def _pg(group):
+    return group.pg if isinstance(group, OrderedGroup) else group
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group, stage: str) -> None:
+    if isinstance(group, OrderedGroup):
+        group.order.issue(group.build, stage, lambda: dist.all_gather_into_tensor(out, inp, group=group.pg))
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
 
 def world_info(group=None) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(group), dist.get_world_size(group)
+        return dist.get_rank(_pg(group)), dist.get_world_size(_pg(group))
     return 0, 1
 
 
@@ -36,7 +120,7 @@ def block_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None, stage: str = "latents") -> torch.Tensor:
     """Concatenate per-rank row blocks of known sizes `counts` (rows may differ by rank)."""
     rank, world = world_info(group)
     if world == 1:
@@ -46,7 +130,7 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch
     padded = torch.zeros(pad_shape, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     out = torch.empty((world,) + pad_shape, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=group)
+    _all_gather(out.view(-1), padded.view(-1), group, stage)
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
 
 
@@ -54,7 +138,7 @@ def gather_latents(z_shard: torch.Tensor, n_total: int, group=None) -> torch.Ten
     """Row shards of the latent set -> the full corpus on every rank."""
     _, world = world_info(group)
     counts = [block_range(n_total, r, world)[1] - block_range(n_total, r, world)[0] for r in range(world)]
-    return all_gather_rows(z_shard.contiguous(), counts, group)
+    return all_gather_rows(z_shard.contiguous(), counts, group, "latents")
 
 
 def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=None, gather_d2: bool = True):
@@ -69,10 +153,10 @@ def sharded_knn(z: torch.Tensor, n_neighbors: int, search_fn: Callable, group=No
     if world == 1:
         return idx, d2
     counts = [block_range(n, r, world)[1] - block_range(n, r, world)[0] for r in range(world)]
-    idx_all = all_gather_rows(idx, counts, group)
+    idx_all = all_gather_rows(idx, counts, group, "knn_idx")
     if gather_d2:
-        return idx_all, all_gather_rows(d2, counts, group)
-    return idx_all, (lambda: all_gather_rows(d2, counts, group))
+        return idx_all, all_gather_rows(d2, counts, group, "knn_d2")
+    return idx_all, (lambda: all_gather_rows(d2, counts, group, "knn_d2"))
 
 
 def chunk_range(n_edges: int, batch_size: int, rank: int, world: int) -> Tuple[int, int]:
@@ -94,7 +178,7 @@ def sharded_edge_lengths(n_edges: int, batch_size: int, length_fn: Callable, gro
     for r in range(world):
         a, b = chunk_range(n_edges, batch_size, r, world)
         counts.append(b - a)
-    return all_gather_rows(local, counts, group)
+    return all_gather_rows(local, counts, group, "edge_lengths")
 
 
 class RunningStatFold:
@@ -133,7 +217,7 @@ class RunningStatFold:
             calls.append(2 * ((b - a + batch_size - 1) // batch_size))
         mine = torch.cat([self.export.tensors[k].flatten() for k in self.KEYS]).contiguous()
         folds = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(folds.view(-1), mine, group=self.group)
+        _all_gather(folds.view(-1), mine, self.group, "bn_fold")
         keep = 1.0 - float(self.export.desc.momentum)
         total = self.r0 * keep ** sum(calls)
         for r in range(self.world):
@@ -156,8 +240,8 @@ def merge_min_argmin(dmin: torch.Tensor, arg: torch.Tensor, offsets: List[int], 
     n = dmin.shape[0]
     all_d = torch.empty((world, n), dtype=dmin.dtype, device=dmin.device)
     all_a = torch.empty((world, n), dtype=arg.dtype, device=arg.device)
-    dist.all_gather_into_tensor(all_d.view(-1), dmin.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_a.view(-1), (arg + offsets[rank]).contiguous(), group=group)
+    _all_gather(all_d.view(-1), dmin.contiguous(), group, "assign_d")
+    _all_gather(all_a.view(-1), (arg + offsets[rank]).contiguous(), group, "assign_a")
     best_d, best_a = all_d[0].clone(), all_a[0].clone()
     for r in range(1, world):                      # ranks own increasing source blocks: strict < keeps the lowest index
         better = all_d[r] < best_d
