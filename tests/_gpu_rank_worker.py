@@ -35,6 +35,17 @@ def main(out_dir):
         dec = SpatialDecoder(1, (256, 128, 64), d, 28, "batch")
         dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         dec = dec.to(dev).train()
+        if os.environ.get("GEO_TEST_MODE") == "in_flight":
+            # five latent sets of different sizes, three sharded builds in flight on every rank (ticket-ordered collectives)
+            from vqvae_amd.scripts.build_codebook import build_codebooks_pipelined
+            sizes = [n, n - 301, n // 2, n - 77, n // 2 + 13]
+            sets = [torch.from_numpy(syn.gauss_latents(m, d, 10 + i)).to(dev) for i, m in enumerate(sizes)]
+            out = build_codebooks_pipelined(sets, dec, depth=3, k=20, sym="union", K=K, init="kpp", seed=42, batch_size=512)
+            np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
+                     **{f"{i}/{key}": np.asarray(r[key]) for i, r in enumerate(out) for key in ("medoids", "assign_flat", "qe")},
+                     **{f"{i}/lengths": r["edge_lengths"].cpu().numpy() for i, r in enumerate(out)},
+                     sharded=np.array([int(all(r["sharded"]["knn"] and r["sharded"]["jvp"] for r in out))]))
+            return
         lo, hi = par.block_range(n, rank, world)
         z = par.gather_latents(torch.from_numpy(z_h[lo:hi]).to(dev), n)        # latents arrive row-sharded
         res = build_codebook_device(z, dec, k=20, sym="union", K=K, init="kpp", seed=42, batch_size=512)

@@ -86,3 +86,48 @@ def test_ranks_on_hip_kernels_equal_single_process(tmp_path, world, shape):
                 assert int(got["bn/" + key]) == int(want)
             else:
                 np.testing.assert_allclose(got["bn/" + key], want, rtol=2e-5, atol=1e-7)
+
+
+def test_sharded_builds_in_flight_equal_single_process(tmp_path):
+    """build_codebooks_pipelined under a process group: every build sharded over two ranks AND three builds in flight per
+    rank (collectives in ticket order, parallel.CollectiveOrder) -- five latent sets of different sizes; every rank must
+    return, for every set, exactly what one process returns for it."""
+    from oracle import metric as om
+    from oracle import synthetic as syn
+    from vqvae_amd._device import device
+    from vqvae_amd.scripts.build_codebook import build_codebook_device
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    world, n, K = 2, 2048, 64
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   GEO_TEST_BACKEND=_backend(world), GEO_TEST_SHAPE=f"{n},16,{K}", GEO_TEST_MODE="in_flight")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    dev = device()
+    sd = om.make_decoder_state(0, 16, 1, norm_type="batch")
+    sizes = [n, n - 301, n // 2, n - 77, n // 2 + 13]
+    for i, m in enumerate(sizes):
+        dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "batch")
+        dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        want = build_codebook_device(torch.from_numpy(syn.gauss_latents(m, 16, 10 + i)).to(dev), dec.to(dev).train(), k=20,
+                                     sym="union", K=K, init="kpp", seed=42, batch_size=512)
+        for rank in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+            assert got["sharded"].tolist() == [1]
+            np.testing.assert_array_equal(got[f"{i}/medoids"], want["medoids"])
+            np.testing.assert_array_equal(got[f"{i}/assign_flat"], want["assign_flat"])
+            np.testing.assert_array_equal(got[f"{i}/lengths"], want["edge_lengths"].cpu().numpy())
+            assert float(got[f"{i}/qe"]) == want["qe"]

@@ -94,15 +94,31 @@ def build_codebook_device(z_flat: torch.Tensor, decoder, *, k: int = 20, sym: st
 def build_codebooks_pipelined(latent_sets, decoder, *, depth: int = 3, **kwargs) -> list:
     """build_codebook_device for several independent latent sets (f32 [n_i, d] on the GPU) with `depth` builds in flight
     (vqvae_amd/pipeline.py): same results as one after the other, 30-45 % more builds per second at the 60 000-latent size.
-    Every slot works on its own copy of the decoder (train-mode BatchNorm updates running statistics in place)."""
+    Every slot works on its own copy of the decoder (train-mode BatchNorm updates running statistics in place).
+    Under an initialised process group every build is sharded over the ranks as usual and the builds in flight issue their
+    collectives in ticket order (parallel.CollectiveOrder: every rank must call this with the same sets in the same order)."""
     import copy
+    from ..parallel import CollectiveOrder, OrderedGroup
     from ..pipeline import run_pipelined
-    if world_info(kwargs.get("group"))[1] > 1:
-        depth = 1                                   # ranks must issue their collectives in the same order
     depth = max(1, min(depth, len(latent_sets)))
     decoders = [decoder] + [copy.deepcopy(decoder) for _ in range(depth - 1)]
     dev = latent_sets[0].device if len(latent_sets) else None
-    return run_pipelined(lambda i, slot: build_codebook_device(latent_sets[i], decoders[slot], **kwargs), len(latent_sets), depth, dev)
+    pg = kwargs.pop("group", None)
+    if world_info(pg)[1] <= 1 or depth == 1:
+        return run_pipelined(lambda i, slot: build_codebook_device(latent_sets[i], decoders[slot], group=pg, **kwargs),
+                             len(latent_sets), depth, dev)
+    order = CollectiveOrder(len(latent_sets), depth)
+
+    def one(i, slot):
+        try:
+            return build_codebook_device(latent_sets[i], decoders[slot], group=OrderedGroup(order, i, pg), **kwargs)
+        except BaseException as e:                  # noqa: BLE001 -- the other builds must not wait for this one's tickets
+            order.abort(e)
+            raise
+        finally:
+            order.finish(i)
+
+    return run_pipelined(one, len(latent_sets), depth, dev)
 
 
 def main(args):
