@@ -123,8 +123,10 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
                                                    const float *__restrict__ M01, const float *__restrict__ b01,
                                                    float *__restrict__ pre, float *__restrict__ tpre,
                                                    double *__restrict__ partial, int want_stats) {
-    __shared__ float zp[TS][DMAX + 1];
-    __shared__ float dz[TS][DMAX + 1];
+    // [latent dimension][sample]: two neighbouring samples of a dimension are one 8-byte broadcast read feeding one packed fma
+    __shared__ __attribute__((aligned(8))) float zp[DMAX][TS];
+    __shared__ __attribute__((aligned(8))) float dz[DMAX][TS];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     __shared__ int valid_s[TS];
     __shared__ double ps[FRONT_MAX_N1][4];                  // per-column statistics before the pixel reduction
     const int tile = blockIdx.x;
@@ -145,14 +147,14 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
                 b = z_end[e * d + k];
             }
         }
-        zp[s][k] = side == 0 ? a : b;
-        dz[s][k] = b - a;
+        zp[k][s] = side == 0 ? a : b;
+        dz[k][s] = b - a;
         if (k == 0) valid_s[s] = ok ? 1 : 0;
     }
     for (int i = threadIdx.x; i < TS * (DMAX - d); i += 256) {      // padded latent columns: zeros, not stale LDS
         const int s = i / (DMAX - d), k = d + i % (DMAX - d);
-        zp[s][k] = 0.f;
-        dz[s][k] = 0.f;
+        zp[k][s] = 0.f;
+        dz[k][s] = 0.f;
     }
     __syncthreads();
     const size_t slot0 = (size_t)tile * TS;
@@ -162,17 +164,22 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
         for (int k = 0; k < DMAX; ++k) m[k] = k < d ? M01[(size_t)k * n1 + n] : 0.f;
         const float bias = b01[n];
         double sx = 0, sxx = 0, st = 0, sxt = 0;
-        for (int s = 0; s < TS; ++s) {
-            float x = bias, t = 0.f;
+        for (int s = 0; s < TS; s += 2) {                      // two samples per packed fma (v_pk_fma_f32): the same fmaf chains
+            f32x2 x2 = {bias, bias}, t2 = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < DMAX; ++k) {
-                x = fmaf(zp[s][k], m[k], x);
-                t = fmaf(dz[s][k], m[k], t);
+                const f32x2 mk = {m[k], m[k]};
+                x2 = __builtin_elementwise_fma(*reinterpret_cast<const f32x2 *>(&zp[k][s]), mk, x2);
+                t2 = __builtin_elementwise_fma(*reinterpret_cast<const f32x2 *>(&dz[k][s]), mk, t2);
             }
-            pre[(slot0 + s) * n1 + n] = x;
-            tpre[(slot0 + s) * n1 + n] = t;
-            if (valid_s[s]) {
-                sx += x; sxx += (double)x * x; st += t; sxt += (double)x * t;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float x = u ? x2.y : x2.x, t = u ? t2.y : t2.x;
+                pre[(slot0 + s + u) * n1 + n] = x;
+                tpre[(slot0 + s + u) * n1 + n] = t;
+                if (valid_s[s + u]) {
+                    sx += x; sxx += (double)x * x; st += t; sxt += (double)x * t;
+                }
             }
         }
         if (want_stats) { ps[n][0] = sx; ps[n][1] = sxx; ps[n][2] = st; ps[n][3] = sxt; }
