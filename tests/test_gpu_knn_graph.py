@@ -356,3 +356,31 @@ def test_cosine_graph_with_a_zero_latent_follows_sklearn(golden):
     assert not (info["indices"][rows] == 17).any()                       # nobody is near the zero latent
     np.testing.assert_allclose(info["distances"][17], g["zero_row_distances"], atol=1e-7)      # all 1.0
     assert W[17].nnz == 10 and np.allclose(W[17].data, 1.0)
+
+
+@pytest.mark.parametrize("d,shift", [(16, 0.0), (32, 0.0), (16, 25.0)])
+def test_two_level_thresholds_from_200k_rows_vs_oracle_and_one_level(d, shift):
+    """From 200 000 rows on the filter's thresholds come from a filtered pass themselves (every 256th row exact, then the
+    matrix-core scan + fp64 refinement over the every-16th-row subset): the lists and fp64 keys must equal the oracle's on
+    sampled rows and, everywhere, those of the one-level scheme (float32 scan, `knn_filter = 2`) -- also far from the
+    origin, where the margins are wide and the lists long."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    from vqvae_amd import _lib
+    n, kq = 210000, 21
+    z = (latents(n, d, 33) + np.float32(shift)).astype(np.float32)
+    out = {}
+    try:
+        for filt in (1, 2):
+            _lib.check(_lib.load().geo_set_option(b"knn_filter", filt), "geo_set_option")
+            idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+            out[filt] = (idx.cpu().numpy(), d2.cpu().numpy())
+    finally:
+        _lib.load().geo_set_option(b"knn_filter", 1)
+    np.testing.assert_array_equal(out[1][0], out[2][0])
+    np.testing.assert_array_equal(out[1][1], out[2][1])
+    for r0, r1 in ((0, 24), (104000, 104024), (n - 24, n)):
+        io, do = _oracle_rows(z, kq, 1 if d > 15 else 0, r0, r1)
+        np.testing.assert_array_equal(out[1][0][r0:r1], io)
+        np.testing.assert_array_equal(out[1][1][r0:r1], do)

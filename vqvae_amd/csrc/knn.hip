@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ zp32
 //    by (distance, index): the result is the one knn_kernel gives.  A query whose list overflows FILTER_CAP (heavily
 //    duplicated points) is reported and the caller falls back to knn_kernel.
 constexpr int FILTER_STRIDE = 16, FILTER_CAP = 1024;
+constexpr int64_t TWO_LEVEL_MIN = 200000;      // from here on the thresholds themselves come from a filtered pass (below)
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void knn_subset_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 
 template <int DPB, int SCAN_CT>
 __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short *__restrict__ zb,
+                                                           const unsigned short *__restrict__ zbq,
                                                            const double *__restrict__ nrm, const double *__restrict__ u,
                                                            int64_t n, int64_t row0, int64_t rows, double eps, int splits,
                                                            int32_t *__restrict__ cnt, int32_t *__restrict__ list) {
@@ -386,8 +388,8 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
         for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xh = __uint_as_float((unsigned)zb[((row0 + q) * 2 + 0) * DPB + ks * 16 + h * 8 + e] << 16);
-                const float xl = __uint_as_float((unsigned)zb[((row0 + q) * 2 + 1) * DPB + ks * 16 + h * 8 + e] << 16);
+                const float xh = __uint_as_float((unsigned)zbq[((row0 + q) * 2 + 0) * DPB + ks * 16 + h * 8 + e] << 16);
+                const float xl = __uint_as_float((unsigned)zbq[((row0 + q) * 2 + 1) * DPB + ks * 16 + h * 8 + e] << 16);
                 ahi[ks][e] = (__bf16)(-2.0f * xh);
                 alo[ks][e] = (__bf16)(-2.0f * xl);
             }
@@ -533,7 +535,8 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
 // kq smallest in (distance, index) order -- the lists are a few hundred entries, unordered
 template <int DCH, bool EXPANSION>
 __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict__ zp32, const double *__restrict__ zq64,
-                                                        const double *__restrict__ nrm, int nch, int kq, int64_t row0,
+                                                        const double *__restrict__ nrm, const double *__restrict__ nrm_q,
+                                                        int nch, int kq, int64_t row0,
                                                         int64_t rows, const int32_t *__restrict__ cnt,
                                                         const int32_t *__restrict__ list, int32_t *__restrict__ idx_out,
                                                         double *__restrict__ d2_out, int32_t *__restrict__ overflow) {
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
         }
         double d2 = acc;
         if (EXPANSION) {
-            d2 = (nrm[qr] + (-2.0 * d2)) + nrm[j];
+            d2 = (nrm_q[qr] + (-2.0 * d2)) + nrm[j];
             if (!(d2 > 0.0)) d2 = 0.0;
         }
         if (valid) { sv[wave][c0 + lane] = d2; si[wave][c0 + lane] = j; }
@@ -659,6 +662,9 @@ extern "C" size_t geo_knn_workspace_bytes(int64_t n, int32_t d) {
         b += geo::align_up(m * p.dp * sizeof(float)) + geo::align_up(m * sizeof(double)) + geo::align_up((size_t)n * 8) +
              geo::align_up((size_t)n * 4) + geo::align_up((size_t)n * FILTER_CAP * 4) + 256 +
              geo::align_up((size_t)n * 2 * dpb * sizeof(unsigned short));
+        const size_t m0 = (m + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        b += geo::align_up(m0 * p.dp * sizeof(float)) + geo::align_up(m0 * sizeof(double)) +
+             geo::align_up(m * 2 * dpb * sizeof(unsigned short));                           // two-level thresholds
     }
     return b;
 }
@@ -703,6 +709,11 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         const int dpb = p.dp < 16 ? 16 : p.dp;
         const bool bf16_scan = geo::options().knn_filter != 2;         // 2: the float32 matrix-core scan (comparison runs)
         unsigned short *zb = ar.take<unsigned short>((size_t)n * 2 * dpb);
+        const size_t m0w = ((size_t)m + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        float *zs0 = ar.take<float>(m0w * p.dp);
+        double *nrm_s0 = ar.take<double>(m0w);
+        unsigned short *zb_s = ar.take<unsigned short>((size_t)m * 2 * dpb);
+        if (!zs0 || !nrm_s0 || !zb_s) zs0 = nullptr;          // (a caller with the older, smaller workspace: one level)
         if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow || !zb) {
             geo::set_error("geo_knn_topk: workspace %zu too small", ws_bytes);
             return GEO_E_WORKSPACE;
@@ -714,35 +725,82 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         GEO_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, stream));
         knn_subset_kernel<<<geo::grid_for(m * p.dp, 256, 4096), 256, 0, stream>>>(zp32, nrm, n, p.dp, FILTER_STRIDE, m, zs32, nrm_s);
         GEO_LAUNCH_CHECK();
-        int rc;
-        if (p.dch == 8) rc = launch_knn<8, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
-        else if (p.dch == 16) rc = launch_knn<16, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
-        else rc = launch_knn<32, 16>(ex, zs32, zq64, nrm_s, nrm, m, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream);
-        if (rc) return rc;
-        knn_tau_kernel<<<geo::grid_for(rows, 256, 4096), 256, 0, stream>>>(d2_out, nrm, row0, rows, n_neighbors, eps, u, cnt);
-        GEO_LAUNCH_CHECK();
-        const int splits = (int)((int64_t)16384 / ((rows + 127) / 128) > 1 ? ((int64_t)16384 / ((rows + 127) / 128) > 64 ? 64 : (int64_t)16384 / ((rows + 127) / 128)) : 1);
-        const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
         if (bf16_scan) {
             knn_split_kernel<<<geo::grid_for((int64_t)n * dpb, 256, 4096), 256, 0, stream>>>(zp32, n, p.dp, dpb, zb);
             GEO_LAUNCH_CHECK();
-            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
-            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
-            else knn_scan_bf16_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+        }
+        const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
+        auto splits_for = [&](int64_t corpus) {                // corpus slices per 128-query block: enough workgroups, tiles to spare
+            const int64_t qb = (rows + 127) / 128;
+            int64_t sp = 16384 / qb;
+            if (sp > 64) sp = 64;
+            if (sp > (corpus + 255) / 256) sp = (corpus + 255) / 256;
+            return (int)(sp > 1 ? sp : 1);
+        };
+#define GEO_EXACT_SUBSET(ZS, NRMS, MS)                                                                              \
+    (p.dch == 8 ? launch_knn<8, 16>(ex, ZS, zq64, NRMS, nrm, MS, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream)    \
+     : p.dch == 16 ? launch_knn<16, 16>(ex, ZS, zq64, NRMS, nrm, MS, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream) \
+                   : launch_knn<32, 16>(ex, ZS, zq64, NRMS, nrm, MS, p.nch, n_neighbors, row0, row1, idx_out, d2_out, stream))
+#define GEO_REFINE(DCHV, EXV, ZC, NRMC) \
+    knn_refine_kernel<DCHV, EXV><<<rgrid, 256, 0, stream>>>(ZC, zq64, NRMC, nrm, p.nch, n_neighbors, row0, rows, cnt, list, \
+                                                          idx_out, d2_out, overflow)
+#define GEO_REFINE_ANY(ZC, NRMC)                                                                                   \
+    do {                                                                                                           \
+        if (p.dch == 8) { if (ex) GEO_REFINE(8, true, ZC, NRMC); else GEO_REFINE(8, false, ZC, NRMC); }              \
+        else if (p.dch == 16) { if (ex) GEO_REFINE(16, true, ZC, NRMC); else GEO_REFINE(16, false, ZC, NRMC); }      \
+        else { if (ex) GEO_REFINE(32, true, ZC, NRMC); else GEO_REFINE(32, false, ZC, NRMC); }                       \
+    } while (0)
+        int rc = 0;
+        bool tau_done = false;
+        // Large inputs: the exact pass over every 16th row is itself N^2 / 16 fp64 work (100 ms of 255 at a million latents).
+        // Two levels instead: thresholds from every 256th row (exact), with them the SAME filter + refinement over the
+        // every-16th-row subset gives the exact kq-th distance to that subset -- the threshold the one-level scheme uses.
+        const int64_t m0 = (m + FILTER_STRIDE - 1) / FILTER_STRIDE;
+        if (bf16_scan && zs0 && n >= TWO_LEVEL_MIN && m0 >= n_neighbors) {
+            knn_subset_kernel<<<geo::grid_for(m0 * p.dp, 256, 4096), 256, 0, stream>>>(zs32, nrm_s, m, p.dp, FILTER_STRIDE, m0, zs0, nrm_s0);
+            GEO_LAUNCH_CHECK();
+            rc = GEO_EXACT_SUBSET(zs0, nrm_s0, m0);
+            if (rc) return rc;
+            knn_tau_kernel<<<geo::grid_for(rows, 256, 4096), 256, 0, stream>>>(d2_out, nrm, row0, rows, n_neighbors, eps, u, cnt);
+            GEO_LAUNCH_CHECK();
+            knn_split_kernel<<<geo::grid_for((int64_t)m * dpb, 256, 4096), 256, 0, stream>>>(zs32, m, p.dp, dpb, zb_s);
+            GEO_LAUNCH_CHECK();
+            const int sp1 = splits_for(m);
+            const unsigned g1 = (unsigned)((rows + 127) / 128) * (unsigned)sp1;
+            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
+            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
+            else knn_scan_bf16_kernel<64, 128><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
+            GEO_LAUNCH_CHECK();
+            GEO_REFINE_ANY(zs32, nrm_s);                       // kq smallest exact distances to the subset -> d2_out
+            GEO_LAUNCH_CHECK();
+            int32_t h_over0 = 0;
+            GEO_HIP_CHECK(hipMemcpyAsync(&h_over0, overflow, 4, hipMemcpyDeviceToHost, stream));
+            GEO_HIP_CHECK(hipStreamSynchronize(stream));
+            tau_done = h_over0 == 0;
+            if (!tau_done) GEO_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, stream));
+        }
+        if (!tau_done) {
+            rc = GEO_EXACT_SUBSET(zs32, nrm_s, m);
+            if (rc) return rc;
+        }
+        knn_tau_kernel<<<geo::grid_for(rows, 256, 4096), 256, 0, stream>>>(d2_out, nrm, row0, rows, n_neighbors, eps, u, cnt);
+        GEO_LAUNCH_CHECK();
+        const int splits = splits_for(n);
+        const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
+        if (bf16_scan) {
+            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+            else knn_scan_bf16_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
         } else
         if (p.dp == 8) knn_scan_kernel<8, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 16) knn_scan_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 32) knn_scan_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else knn_scan_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         GEO_LAUNCH_CHECK();
-        const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
-#define GEO_REFINE(DCHV, EXV) \
-    knn_refine_kernel<DCHV, EXV><<<rgrid, 256, 0, stream>>>(zp32, zq64, nrm, p.nch, n_neighbors, row0, rows, cnt, list, \
-                                                          idx_out, d2_out, overflow)
-        if (p.dch == 8) { if (ex) GEO_REFINE(8, true); else GEO_REFINE(8, false); }
-        else if (p.dch == 16) { if (ex) GEO_REFINE(16, true); else GEO_REFINE(16, false); }
-        else { if (ex) GEO_REFINE(32, true); else GEO_REFINE(32, false); }
+        GEO_REFINE_ANY(zp32, nrm);
+#undef GEO_REFINE_ANY
 #undef GEO_REFINE
+#undef GEO_EXACT_SUBSET
         GEO_LAUNCH_CHECK();
         int32_t h_over = 0;
         GEO_HIP_CHECK(hipMemcpyAsync(&h_over, overflow, 4, hipMemcpyDeviceToHost, stream));
