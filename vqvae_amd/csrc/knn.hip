@@ -373,7 +373,9 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     constexpr int KST = DPB / 16;                              // MFMA k-steps
     constexpr int ROWB = 2 * DPB * 2 + 16;                     // bytes per candidate in LDS: hi, lo, 16 of padding (banks)
     __shared__ __attribute__((aligned(16))) unsigned char Ts[2][SCAN_CT * ROWB];
-    __shared__ float Ns[2][SCAN_CT];
+    // |x_j|^2 (1 - eps) rounded down to float32, as three exact bf16 parts: it enters the accumulator through one more MFMA
+    // (A = ones in k = 0..2, B = the parts) instead of 32 vector subtractions per 2 048 pairs
+    __shared__ uint2 Nb[2][SCAN_CT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t qbase = (int64_t)(blockIdx.x / splits) * 128 + wave * 32;   // this wave's 32 queries (local row numbers)
@@ -402,9 +404,15 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
                 ur = (float)ud;
                 if ((double)ur < ud) ur = nextafterf(ur, 3.4e38f);
             }
-            uq[qq] = ur;
+            uq[qq] = -ur;                                      // the accumulator starts at -u (the MFMA's C operand)
         }
     }
+    f32x16v negu;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) negu[qq] = uq[qq];
+    bf16x8k aone;                                              // A[m][k] = 1 for k = 0, 1, 2 (lanes of the first k half)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aone[e] = (__bf16)((h == 0 && e < 3) ? 1.0f : 0.0f);
     const int64_t all_tiles = (n + SCAN_CT - 1) / SCAN_CT, per_split = (all_tiles + splits - 1) / splits;
     const int64_t tile_lo = per_split * split;
     const int64_t n_tiles = tile_lo + per_split < all_tiles ? tile_lo + per_split : all_tiles;
@@ -442,7 +450,13 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
             const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
             *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + off * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
         }
-        if (threadIdx.x < SCAN_CT) Ns[buf][threadIdx.x] = nval;
+        if (threadIdx.x < SCAN_CT) {
+            const unsigned b1 = __float_as_uint(nval) & 0xffff0000u;
+            const float r1 = nval - __uint_as_float(b1);                   // exact
+            const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(b2);                     // exact, at most 8 significant bits left
+            Nb[buf][threadIdx.x] = make_uint2((b1 >> 16) | b2, __float_as_uint(r2) >> 16);
+        }
     };
     constexpr int EQ_CAP = 128;
     __shared__ unsigned long long eb[4][EQ_CAP];
@@ -470,22 +484,21 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
 #pragma unroll
         for (int q = 0; q < 16; ++q) any |= __float_as_uint(acc0[q]) | __float_as_uint(acc1[q]);
         if (!__ballot((any & 0x80000000u) != 0)) return;       // wave-uniform: nothing to keep in these 2 048 pairs
-        unsigned bits = 0;                                     // bit q: acc0[q] < 0, bit 16 + q: acc1[q] < 0
+        unsigned bits = 0;                                     // bit 31 - q: acc0[q] < 0, bit 15 - q: acc1[q] < 0
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            bits |= (__float_as_uint(acc0[q]) >> 31) << q;
-            bits |= (__float_as_uint(acc1[q]) >> 31) << (16 + q);
-        }
+        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc0[q]), 31);   // (bits << 1) | sign
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc1[q]), 31);
         for (;;) {
             const unsigned long long hit = __ballot(bits != 0);
             if (!hit) break;
             if (bits != 0) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
-                const int q = b & 15;
+                const int q = 15 - (b & 15);
                 const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
                 const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const int32_t cand = (int32_t)(cand0 + (b >> 4) * 32 + r);
+                const int32_t cand = (int32_t)(cand0 + (1 - (b >> 4)) * 32 + r);
                 if (pos < EQ_CAP) {
                     eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
                 } else {                                       // queue full (masses of duplicates): straight to the list
@@ -505,9 +518,13 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
 #pragma unroll
         for (int t = 0; t < SCAN_CT / 32; t += 2) {           // two column tiles in flight: independent accumulators
             f32x16v acc0, acc1;
-            const float n0 = Ns[buf][t * 32 + r], n1 = Ns[buf][(t + 1) * 32 + r];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = n0 - uq[i]; acc1[i] = n1 - uq[i]; }
+            {
+                uint2 n0 = Nb[buf][t * 32 + r], n1 = Nb[buf][(t + 1) * 32 + r];
+                if (h) { n0 = make_uint2(0u, 0u); n1 = n0; }
+                const uint4 f0 = make_uint4(n0.x, n0.y, 0u, 0u), f1 = make_uint4(n1.x, n1.y, 0u, 0u);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aone, *reinterpret_cast<const bf16x8k *>(&f0), negu, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aone, *reinterpret_cast<const bf16x8k *>(&f1), negu, 0, 0, 0);
+            }
             const unsigned char *b0 = &Ts[buf][(t * 32 + r) * ROWB + h * 16], *b1 = b0 + 32 * ROWB;
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
