@@ -131,3 +131,15 @@ def test_sharded_builds_in_flight_equal_single_process(tmp_path):
             np.testing.assert_array_equal(got[f"{i}/assign_flat"], want["assign_flat"])
             np.testing.assert_array_equal(got[f"{i}/lengths"], want["edge_lengths"].cpu().numpy())
             assert float(got[f"{i}/qe"]) == want["qe"]
+
+
+def test_rccl_accepts_ticket_ordered_collectives_from_pipeline_threads():
+    """What one GPU can say about the RCCL side of sharded builds in flight: a ONE-rank nccl (= RCCL) group, three host
+    threads on their own HIP streams, their builds' all-gathers issued through CollectiveOrder on the one communicator --
+    ProcessGroupNCCL must take the calls from several threads, and the gathers must be ordered with the kernels of the
+    calling thread's stream (tests/_gpu_rccl_threads_worker.py).  The multi-rank order itself is tested over gloo."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_rccl_threads_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.stdout[-1500:], out.stderr[-3000:])
