@@ -253,6 +253,11 @@ typedef struct geo_decoder_desc {
 } geo_decoder_desc;
 
 size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size);
+/* Workspace of geo_decoder_jvp_edges including the per-latent buffers (primal ConvT2 output and output sigmoids of every
+ * latent) that decoders with fixed statistics use: the primal pass then runs once per latent instead of once per edge end
+ * (what riemannian_metric.py:57-58 recomputes for every edge).  A workspace of geo_jvp_workspace_bytes() still works: the
+ * call then takes the per-edge-end path. */
+size_t geo_jvp_edges_workspace_bytes(const geo_decoder_desc *dec, int64_t n_nodes, int64_t n_edges, int32_t batch_size);
 int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes,
                           const int32_t *src, const int32_t *dst, int64_t n_edges, int32_t batch_size,
                           float *len_out, void *ws, size_t ws_bytes, void *stream);

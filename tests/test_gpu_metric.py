@@ -253,3 +253,43 @@ def test_weight_stationary_convt2_kernel_agrees_with_the_tile_resident_one(n_edg
         assert (rel <= TOL).mean() >= 0.999, (mid, (rel <= TOL).mean())
     close = np.abs(out[0] - out[4]) <= 2e-6 * np.abs(out[0])
     assert close.mean() >= 0.999, close.mean()               # (a ReLU at float32 rounding distance from zero may flip)
+
+
+@pytest.mark.parametrize("norm,training,d,cout,size,n_nodes,n_edges,bs", [
+    ("batch", False, 16, 1, 28, 3000, 20000, 512),      # BatchNorm in eval mode, more edges than one pass of chunks has tiles
+    ("none", True, 16, 1, 28, 777, 5001, 100),          # no norm layer, ragged sizes
+    ("batch", False, 64, 3, 32, 1500, 6000, 512),       # wide latents (matrix-core first layer), 192-output head
+])
+def test_per_node_primal_is_bit_identical_to_the_per_edge_end_path(norm, training, d, cout, size, n_nodes, n_edges, bs, request):
+    """Decoders with fixed statistics: the primal pass runs once per LATENT (`jvp_per_node`, default on; SURVEY 2.1 K4'), the edge
+    slots carry the tangent alone and take ReLU masks / sigmoid' from their node's rows.  Same products in the same order: the
+    lengths of the edge-list entry point must equal the per-edge-end path's (option off, and the pairs entry point) bit for bit,
+    and pass the usual gate of the fp64 closed form."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_device, edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder
+    dev = device()
+    sd = om.make_decoder_state(9, d, cout, norm_type=norm)
+    dec = SpatialDecoder(cout, (256, 128, 64), d, size, norm)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(dev)
+    dec = dec.train() if training else dec.eval()
+    r = np.random.RandomState(n_edges)
+    z_h = r.randn(n_nodes, d).astype(np.float32)
+    src_h = r.randint(0, n_nodes, n_edges).astype(np.int32)
+    dst_h = (src_h + 1 + r.randint(0, n_nodes - 1, n_edges)).astype(np.int32) % n_nodes
+    z, src, dst = (torch.from_numpy(a).to(dev) for a in (z_h, src_h, dst_h))
+    ex = DecoderExport(dec, dev)
+    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_per_node", 1))
+    out = {}
+    for mode in (1, 0):
+        _lib.check(_lib.load().geo_set_option(b"jvp_per_node", mode), "geo_set_option")
+        out[mode] = edge_lengths_graph_device(ex, z, src, dst, bs).cpu().numpy()
+    pairs = edge_lengths_device(ex, z[src.long()].contiguous(), z[dst.long()].contiguous(), bs).cpu().numpy()
+    np.testing.assert_array_equal(out[1], out[0])
+    np.testing.assert_array_equal(out[1], pairs)
+    ref64 = om.edge_lengths(sd, norm, size, z_h[src_h], z_h[dst_h], bs, training, dtype=torch.float64).numpy()
+    rel = np.abs(out[1] - ref64) / np.abs(ref64)
+    assert (rel <= TOL).mean() >= 0.999, (rel <= TOL).mean()

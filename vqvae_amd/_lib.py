@@ -56,6 +56,7 @@ _SIGNATURES = {
     "geo_csr_compact_count": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p, sz, c_p]),
     "geo_csr_compact_fill": (ctypes.c_int, [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p, c_p, c_p, c_p]),
     "geo_jvp_workspace_bytes": (sz, [ctypes.POINTER(DecoderDesc), i64, i32]),
+    "geo_jvp_edges_workspace_bytes": (sz, [ctypes.POINTER(DecoderDesc), i64, i64, i32]),
     "geo_decoder_jvp_edges": (ctypes.c_int, [ctypes.POINTER(DecoderDesc), c_p, i64, c_p, c_p, i64, i32, c_p, c_p, sz, c_p]),
     "geo_decoder_jvp_pairs": (ctypes.c_int, [ctypes.POINTER(DecoderDesc), c_p, c_p, i64, i32, c_p, c_p, sz, c_p]),
     "geo_gather_edge_weights": (ctypes.c_int, [c_p, c_p, i64, c_p, c_p]),

@@ -675,7 +675,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // {1,2,5,6} (10 of the 20 (pixel, chunk) products each, 2 or 3 per pixel): 4 x 2 accumulator tiles = 128
 // registers per wave, so two waves share a SIMD and one's weight-fragment loads (L2) hide behind the other's
 // MFMAs.
-template <int C1, bool GN>
+// TONLY: tangent stream only -- decoders with fixed statistics (no norm, BatchNorm in eval mode) get the primal ConvT2 output
+// once per LATENT from a separate launch over the nodes (run_jvp, "per-node primal"); here the primal pre-activation only
+// decides the ReLU mask of the tangent.
+template <int C1, bool GN, bool TONLY = false>
 __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
                                                         const NormConst *__restrict__ consts1, int consts_per_group,
                                                         int tiles_per_group, ChunkTable tab, int c2,
@@ -750,11 +753,11 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                 norm_relu(kA, rp[i].x, rt[i].x, &a0, &t0);
                 norm_relu(kB, rp[i].y, rt[i].y, &a1, &t1);
                 unsigned wa[3], wt[3];
-                split3_pair(a0, a1, wa[0], wa[1], wa[2]);
+                if (!TONLY) split3_pair(a0, a1, wa[0], wa[1], wa[2]);
                 split3_pair(t0, t1, wt[0], wt[1], wt[2]);
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    *reinterpret_cast<unsigned *>(&A3[buf][part][0][s0p + i][k0p]) = wa[part];
+                    if (!TONLY) *reinterpret_cast<unsigned *>(&A3[buf][part][0][s0p + i][k0p]) = wa[part];
                     *reinterpret_cast<unsigned *>(&A3[buf][part][1][s0p + i][k0p]) = wt[part];
                 }
             }
@@ -772,14 +775,14 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                 float a, ta;
                 if (GN) norm_relu_gn(k < CPT / 2 ? gg0 : gg1, kc[k0 + k].sc, kc[k0 + k].beta, rawp[k], rawt[k], &a, &ta);
                 else norm_relu(kc[k0 + k], rawp[k], rawt[k], &a, &ta);
-                split3(a, pp[0][k], pp[1][k], pp[2][k]);
+                if (!TONLY) split3(a, pp[0][k], pp[1][k], pp[2][k]);
                 split3(ta, pt[0][k], pt[1][k], pt[2][k]);
             }
 #pragma unroll
             for (int part = 0; part < 3; ++part)
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
-                    A3[buf][part][0][ss][k0 + k] = pp[part][k];
+                    if (!TONLY) A3[buf][part][0][ss][k0 + k] = pp[part][k];
                     A3[buf][part][1][ss][k0 + k] = pt[part][k];
                 }
             if (ip < 3) {
@@ -811,20 +814,20 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                 bf16x8 ap[3], at[3];
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][0][r][ks * 16 + h * 8]);
+                    if (!TONLY) ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][0][r][ks * 16 + h * 8]);
                     at[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][1][r][ks * 16 + h * 8]);
                 }
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct[lc], 0, 0, 0);
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct[lc], 0, 0, 0);
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct[lc], 0, 0, 0);
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct[lc], 0, 0, 0);
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct[lc], 0, 0, 0);
-                accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[lc], 0, 0, 0);
+                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[lc], 0, 0, 0);
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[lc], 0, 0, 0);
             }
         }
@@ -847,9 +850,9 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
             const float x = accp[lc][q] + bias, t = acct[lc][q];
-            pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
+            if (!TONLY) pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = x;
             tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = t;
-            if (row < n_valid) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
+            if (!TONLY && row < n_valid) { sx += x; sxx += (double)x * x; st_ += t; sxt += (double)x * t; }
         }
     }
     if (want_stats) {
@@ -1332,13 +1335,20 @@ __global__ __launch_bounds__(256) void pack_back_bf16_kernel(const float *__rest
     }
 }
 
-template <int NT, bool GN>
+// MODE 0: primal + tangent of every slot -> |J dz| per slot.
+// Per-node primal (decoders with fixed statistics; run_jvp): MODE 2 runs over the LATENTS, primal only, and stores the
+// sigmoid of every output (sg_node [node][NP]); MODE 1 runs over the edge slots, tangent only: the ReLU mask comes from the
+// slot's node row of pre2 (gathered), sigmoid' from sg_node -- the same products in the same order as MODE 0.
+template <int NT, bool GN, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restrict__ pre2, const float *__restrict__ tpre2,
                                                        const NormConst *__restrict__ consts2, int consts_per_group,
                                                        int tiles_per_group, int co_n, int s_out,
                                                        const unsigned short *__restrict__ W3b,
                                                        const float *__restrict__ b3, float *__restrict__ norms,
-                                                       const float4 *__restrict__ gs2) {
+                                                       const float4 *__restrict__ gs2, float *__restrict__ sg_node = nullptr,
+                                                       const int32_t *__restrict__ src = nullptr,
+                                                       const int32_t *__restrict__ dst = nullptr, int64_t e_base = 0,
+                                                       int64_t n_edges = 0, int batch = 1) {
     constexpr int C2 = 64, KB = 128, LDK = KB + 8, NP = NT * 32;
     __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];     // 52 KB, reused for the reduction
     __shared__ NormConst kc[C2];
@@ -1360,11 +1370,19 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
 
     const int r = lane & 31, h = lane >> 5;
     const int ss = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 16;
+    // MODE 1: the latent a slot belongs to (start side: src, end side: dst; padding slots read latent 0, their result is unused)
+    auto node_of = [&](int sample) -> size_t {
+        const int tg = tile - group * tiles_per_group;
+        const int64_t e = e_base + (int64_t)(group >> 1) * batch + (int64_t)tg * TS + sample;
+        if (tg * TS + sample >= batch || e >= n_edges) return 0;
+        return (size_t)((group & 1) ? dst[e] : src[e]);
+    };
+    const size_t prow = MODE == 1 ? node_of(ss) : slot0 + ss;      // row of the primal pre-activations this thread stages
     for (int kb = 0; kb < 8; ++kb) {
         __syncthreads();
         {
-            const float *xp = pre2 + (slot0 + ss) * n2 + (size_t)kb * KB + k0;
-            const float *xt = tpre2 + (slot0 + ss) * n2 + (size_t)kb * KB + k0;
+            const float *xp = pre2 + prow * n2 + (size_t)kb * KB + k0;
+            const float *xt = (MODE == 2 ? pre2 : tpre2) + (slot0 + ss) * n2 + (size_t)kb * KB + k0;
 #pragma unroll
             for (int k8 = 0; k8 < 16; k8 += 8) {
                 u16x8 pp[3], pt[3];
@@ -1375,15 +1393,13 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
                     if (GN) norm_relu_gn(gsl[GN ? ss : 0][c >> 1], kc[c].sc, kc[c].beta, xp[k8 + k], xt[k8 + k], &a, &ta);
                     else norm_relu(kc[c], xp[k8 + k], xt[k8 + k], &a, &ta);
                     unsigned short q1, q2, q3;
-                    split3(a, q1, q2, q3);
-                    pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3;
-                    split3(ta, q1, q2, q3);
-                    pt[0][k] = q1; pt[1][k] = q2; pt[2][k] = q3;
+                    if (MODE != 1) { split3(a, q1, q2, q3); pp[0][k] = q1; pp[1][k] = q2; pp[2][k] = q3; }
+                    if (MODE != 2) { split3(ta, q1, q2, q3); pt[0][k] = q1; pt[1][k] = q2; pt[2][k] = q3; }
                 }
 #pragma unroll
                 for (int part = 0; part < 3; ++part) {
-                    *reinterpret_cast<u16x8 *>(&A3[part][0][ss][k0 + k8]) = pp[part];
-                    *reinterpret_cast<u16x8 *>(&A3[part][1][ss][k0 + k8]) = pt[part];
+                    if (MODE != 1) *reinterpret_cast<u16x8 *>(&A3[part][0][ss][k0 + k8]) = pp[part];
+                    if (MODE != 2) *reinterpret_cast<u16x8 *>(&A3[part][1][ss][k0 + k8]) = pt[part];
                 }
             }
         }
@@ -1394,8 +1410,8 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
             bf16x8 ap[3], at[3];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
-                at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
+                if (MODE != 1) ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][0][r][ks * 16 + h * 8]);
+                if (MODE != 2) at[part] = *reinterpret_cast<const bf16x8 *>(&A3[part][1][r][ks * 16 + h * 8]);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -1404,24 +1420,25 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
                 for (int part = 0; part < 3; ++part)
                     b[part] = *reinterpret_cast<const bf16x8 *>(
                         W3b + ((((size_t)kb * 3 + part) * 8 + ks) * 2 + h) * (size_t)NP * 8 + (size_t)(nt * 32 + r) * 8);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0], acct[nt], 0, 0, 0);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2], acct[nt], 0, 0, 0);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1], acct[nt], 0, 0, 0);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0], acct[nt], 0, 0, 0);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1], acct[nt], 0, 0, 0);
-                accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0], accp[nt], 0, 0, 0);
-                acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1], acct[nt], 0, 0, 0);
+                if (MODE != 1) accp[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0], accp[nt], 0, 0, 0);
+                if (MODE != 2) acct[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0], acct[nt], 0, 0, 0);
             }
         }
     }
     // sum the four waves' partial tiles through LDS (one 32-column tile at a time), then sigmoid' and the norm
     float *red = reinterpret_cast<float *>(&A3[0][0][0][0]);     // [wave 4][p|t 2][32 rows][33]
     const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const size_t nrow = MODE == 1 ? node_of(row) : slot0 + row;    // sg_node row: the slot's latent (1) / this latent (2)
     double sumsq = 0.0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1429,8 +1446,8 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int rr = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            red[((wave * 2 + 0) * 32 + rr) * 33 + (lane & 31)] = accp[nt][q];
-            red[((wave * 2 + 1) * 32 + rr) * 33 + (lane & 31)] = acct[nt][q];
+            if (MODE != 1) red[((wave * 2 + 0) * 32 + rr) * 33 + (lane & 31)] = accp[nt][q];
+            if (MODE != 2) red[((wave * 2 + 1) * 32 + rr) * 33 + (lane & 31)] = acct[nt][q];
         }
         __syncthreads();
 #pragma unroll
@@ -1440,10 +1457,11 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
                 float x = b3[o / (s_out * s_out)], t = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    x += red[((w * 2 + 0) * 32 + row) * 33 + c4 + c];
-                    t += red[((w * 2 + 1) * 32 + row) * 33 + c4 + c];
+                    if (MODE != 1) x += red[((w * 2 + 0) * 32 + row) * 33 + c4 + c];
+                    if (MODE != 2) t += red[((w * 2 + 1) * 32 + row) * 33 + c4 + c];
                 }
-                const float sg = 1.0f / (1.0f + expf(-x));
+                const float sg = MODE == 1 ? sg_node[nrow * NP + o] : 1.0f / (1.0f + expf(-x));
+                if (MODE == 2) sg_node[nrow * NP + o] = sg;
                 const float j = t * sg * (1.0f - sg);
                 sumsq += (double)(j * j);
             }
@@ -1452,7 +1470,7 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
     sumsq += __shfl_xor(sumsq, 1, 64);
     sumsq += __shfl_xor(sumsq, 2, 64);
     sumsq += __shfl_xor(sumsq, 4, 64);
-    if ((threadIdx.x & 7) == 0) norms[slot0 + row] = (float)sqrt(sumsq);
+    if (MODE != 2 && (threadIdx.x & 7) == 0) norms[slot0 + row] = (float)sqrt(sumsq);
 }
 
 __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ norms, int64_t e_base, int64_t e_count,
@@ -1541,6 +1559,15 @@ struct Plan {
 
 constexpr int64_t MAX_SLOTS_PER_PASS = 1 << 21;      // bounds the activation workspace (~25 GB at the shipped sizes)
 
+// bytes of the per-node primal buffers (pre2 of every latent + the sigmoid of every output), 0 when the decoder / sizes do not
+// take that path
+size_t node_bytes(const Shape &s, int64_t n_nodes) {
+    if (n_nodes <= 0) return 0;
+    const size_t node_slots = ((size_t)n_nodes + TS - 1) / TS * TS;
+    const size_t np = (size_t)((s.p_out + 31) / 32) * 32;
+    return geo::align_up(node_slots * s.n2 * 4) + geo::align_up(node_slots * np * 4);
+}
+
 bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) {
     if (!make_shape(dc, &p->sh)) return false;
     p->batch = batch;
@@ -1570,9 +1597,9 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     return true;
 }
 
-int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, const int32_t *dst, const float *z_start,
-            const float *z_end, int64_t n_edges, int32_t batch, float *len_out, void *ws, size_t ws_bytes,
-            hipStream_t stream) {
+int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const int32_t *src, const int32_t *dst,
+            const float *z_start, const float *z_end, int64_t n_edges, int32_t batch, float *len_out, void *ws,
+            size_t ws_bytes, hipStream_t stream) {
     GEO_REQUIRE(dc && len_out && ws, "geo_decoder_jvp: null pointer");
     GEO_REQUIRE(batch > 0, "geo_decoder_jvp: batch_size must be positive");
     if (n_edges == 0) return GEO_OK;
@@ -1615,6 +1642,15 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         GEO_REQUIRE(gs2 != nullptr, "geo_decoder_jvp: workspace carve failed");
     }
     GEO_REQUIRE(slot_valid != nullptr, "geo_decoder_jvp: workspace carve failed");
+    // per-node primal (see below): the buffers exist when the caller sized the workspace with geo_jvp_edges_workspace_bytes
+    const size_t node_slots = n_nodes > 0 ? ((size_t)n_nodes + TS - 1) / TS * TS : 0;
+    const size_t np_pad = (size_t)((s.p_out + 31) / 32) * 32;
+    float *pre2_node = nullptr, *sg_node = nullptr;
+    if (node_slots && node_slots <= slots && ws_bytes >= pl.bytes + node_bytes(s, n_nodes)) {
+        pre2_node = ar.take<float>(node_slots * s.n2);
+        sg_node = ar.take<float>(node_slots * np_pad);
+        if (!sg_node) pre2_node = nullptr;
+    }
 
     ChunkTable tab;
     make_chunks(s, &tab);
@@ -1669,6 +1705,50 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
         finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c1, dc->norm, dc->g1, dc->be1, dc->rm1, dc->rv1, dc->eps, k1);
         GEO_LAUNCH_CHECK();
         finalize_fixed_kernel<<<1, 256, 0, stream>>>(s.c2, dc->norm, dc->g2, dc->be2, dc->rm2, dc->rv2, dc->eps, k2);
+        GEO_LAUNCH_CHECK();
+    }
+    // Per-node primal (round-2 review: "pre-activations depend on the node only"): with FIXED statistics (no norm layer,
+    // BatchNorm in eval mode) the whole primal pass is a function of the latent, not of the edge -- 60 000 rows instead of
+    // 1.89 M edge ends.  One launch sequence over the latents keeps pre2 and the output sigmoids per node; the edge slots then
+    // carry the tangent alone (ConvT2 and ConvT3 at half the matrix work, no primal stores), taking the ReLU masks and
+    // sigmoid' from their node's rows.  Same products in the same order: lengths are bit-identical to the per-slot path
+    // (`jvp_per_node = 0`).  Train-mode BatchNorm (batch statistics change with the chunk) and GroupNorm's tangent (statistics
+    // of the tangent itself) keep the per-slot path.
+    const bool mid_all_path = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 && mid_opt != 2 && !mid_stat;
+    const bool per_node = !batch_stats && dc->norm != 2 && src && dst && pre2_node && mid_all_path && back_mfma &&
+                          geo::options().jvp_per_node != 0;
+    if (per_node) {
+        const int64_t nt_node = (int64_t)(node_slots / TS);
+        const int big_batch = (int)node_slots;                  // one group: every latent on the "start" side
+#define GEO_FRONT_N(DM)                                                                                            \
+    front_kernel<DM><<<(unsigned)nt_node, 256, 0, stream>>>(nullptr, nullptr, nullptr, z, z, 0, n_nodes, big_batch,   \
+                                                            (int)nt_node, s.d, s.n1, M01, b01, pre1, tpre1, part1, 0)
+#define GEO_FRONT_MFMA_N(DM)                                                                                       \
+    front_mfma_kernel<DM><<<(unsigned)nt_node, 256, 0, stream>>>(nullptr, nullptr, nullptr, z, z, 0, n_nodes,         \
+                                                                 big_batch, (int)nt_node, s.d, s.n1, M01, b01, pre1,  \
+                                                                 tpre1, part1, 0)
+        const bool front_mfma_n = s.d > 16 && s.n1 % 32 == 0 && geo::options().jvp_front_valu == 0;
+        if (s.d <= 16) GEO_FRONT_N(16);
+        else if (s.d <= 32) { if (front_mfma_n) GEO_FRONT_MFMA_N(32); else GEO_FRONT_N(32); }
+        else { if (front_mfma_n) GEO_FRONT_MFMA_N(64); else GEO_FRONT_N(64); }
+#undef GEO_FRONT_MFMA_N
+#undef GEO_FRONT_N
+        GEO_LAUNCH_CHECK();
+#define GEO_MIDA_N(C1V)                                                                                            \
+    mid_all_kernel<C1V, false><<<(unsigned)nt_node, 512, 0, stream>>>(pre1, tpre1, k1, 0, (int)nt_node, tab, s.c2, B3,  \
+                                                                      dc->b2, pre2_node, tpre2, part2, 0, slot_valid, \
+                                                                      nullptr, 0, n_nodes, big_batch)
+        if (s.c1 == 128) GEO_MIDA_N(128);
+        else if (s.c1 == 64) GEO_MIDA_N(64);
+        else GEO_MIDA_N(32);
+#undef GEO_MIDA_N
+        GEO_LAUNCH_CHECK();
+        if (back_nt == 1)
+            back_mfma_kernel<1, false, 2><<<(unsigned)nt_node, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, (int)nt_node, s.co,
+                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node);
+        else
+            back_mfma_kernel<6, false, 2><<<(unsigned)nt_node, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, (int)nt_node, s.co,
+                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node);
         GEO_LAUNCH_CHECK();
     }
     const int64_t total_chunks = (n_edges + batch - 1) / batch;
@@ -1726,6 +1806,15 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
             mid_stat_kernel<128><<<256, 256, stat_lds_bytes, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_groups,
                                                           units, slots_tab, Bs, dc->b2, pre2, tpre2, part2,
                                                           batch_stats ? 1 : 0, e_base, n_edges, batch);
+        } else if (mid_all && per_node) {
+#define GEO_MIDA_T(C1V)                                                                                            \
+    mid_all_kernel<C1V, false, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group, tab, \
+                                                                            s.c2, B3, dc->b2, pre2, tpre2, part2, 0,   \
+                                                                            slot_valid, nullptr, e_base, n_edges, batch)
+            if (s.c1 == 128) GEO_MIDA_T(128);
+            else if (s.c1 == 64) GEO_MIDA_T(64);
+            else GEO_MIDA_T(32);
+#undef GEO_MIDA_T
         } else if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
@@ -1770,7 +1859,15 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, const int32_t *src, cons
     back_mfma_kernel<NTV, GNV><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,         \
                                                                       pl.tiles_per_group, s.co, s.s_out, W3b,       \
                                                                       dc->b3, norms, gs2)
-        if (back_mfma && back_nt == 1) { if (gs2) GEO_BACK(1, true); else GEO_BACK(1, false); }
+        if (per_node && back_nt == 1)
+            back_mfma_kernel<1, false, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co,
+                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node,
+                                                                                 src, dst, e_base, n_edges, batch);
+        else if (per_node)
+            back_mfma_kernel<6, false, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co,
+                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node,
+                                                                                 src, dst, e_base, n_edges, batch);
+        else if (back_mfma && back_nt == 1) { if (gs2) GEO_BACK(1, true); else GEO_BACK(1, false); }
         else if (back_mfma) { if (gs2) GEO_BACK(6, true); else GEO_BACK(6, false); }
 #undef GEO_BACK
         else
@@ -1798,11 +1895,18 @@ extern "C" size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n
     return pl.bytes;
 }
 
+extern "C" size_t geo_jvp_edges_workspace_bytes(const geo_decoder_desc *dec, int64_t n_nodes, int64_t n_edges,
+                                                int32_t batch_size) {
+    Plan pl;
+    if (!dec || batch_size <= 0 || n_edges < 0 || n_nodes < 0 || !make_plan(dec, n_edges, batch_size, &pl)) return 0;
+    return pl.bytes + node_bytes(pl.sh, n_nodes);
+}
+
 extern "C" int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes, const int32_t *src,
                                      const int32_t *dst, int64_t n_edges, int32_t batch_size, float *len_out, void *ws,
                                      size_t ws_bytes, void *stream) {
     GEO_REQUIRE(n_edges == 0 || (z && src && dst && n_nodes > 0), "geo_decoder_jvp_edges: null pointer");
-    return run_jvp(dec, z, src, dst, nullptr, nullptr, n_edges, batch_size, len_out, ws, ws_bytes,
+    return run_jvp(dec, z, n_nodes, src, dst, nullptr, nullptr, n_edges, batch_size, len_out, ws, ws_bytes,
                    static_cast<hipStream_t>(stream));
 }
 
@@ -1810,6 +1914,6 @@ extern "C" int geo_decoder_jvp_pairs(const geo_decoder_desc *dec, const float *z
                                      int64_t n_edges, int32_t batch_size, float *len_out, void *ws, size_t ws_bytes,
                                      void *stream) {
     GEO_REQUIRE(n_edges == 0 || (z_start && z_end), "geo_decoder_jvp_pairs: null pointer");
-    return run_jvp(dec, nullptr, nullptr, nullptr, z_start, z_end, n_edges, batch_size, len_out, ws, ws_bytes,
+    return run_jvp(dec, nullptr, 0, nullptr, nullptr, z_start, z_end, n_edges, batch_size, len_out, ws, ws_bytes,
                    static_cast<hipStream_t>(stream));
 }

@@ -51,9 +51,10 @@ def edge_lengths_graph_device(export: DecoderExport, z: torch.Tensor, src: torch
     out = torch.empty(E, dtype=torch.float32, device=dev)
     if E == 0:
         return out
-    nbytes = lib.geo_jvp_workspace_bytes(export.desc, E, int(batch_size))
+    # (with the per-latent buffers: decoders with fixed statistics run their primal pass once per latent, not per edge end)
+    nbytes = lib.geo_jvp_edges_workspace_bytes(export.desc, int(z.shape[0]), E, int(batch_size))
     if nbytes == 0:
-        raise _lib.GeoHipError("geo_jvp_workspace_bytes: decoder configuration not supported by the HIP path")
+        raise _lib.GeoHipError("geo_jvp_edges_workspace_bytes: decoder configuration not supported by the HIP path")
     ws = workspace(nbytes, dev)
     with torch.cuda.device(dev):
         _lib.check(lib.geo_decoder_jvp_edges(export.desc, ptr(z), z.shape[0], ptr(src), ptr(dst), E, int(batch_size),
