@@ -744,8 +744,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
         gg1 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2 + 1];
     }
     __syncthreads();                                           // kc visible
-    for (int ip = 0; ip < 4; ++ip) {
-        const int buf = ip & 1;
+    // stage_px(buf, nx): normalise + ReLU + split the raw values held in registers into A3[buf], then fetch pixel nx's (nx < 4)
+    auto stage_px = [&](int buf, int nx) {
         if (PAIR) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -761,11 +761,11 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                     *reinterpret_cast<unsigned *>(&A3[buf][part][1][s0p + i][k0p]) = wt[part];
                 }
             }
-            if (ip < 3) {
+            if (nx < 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)(ip + 1) * C1 + k0p);
-                    rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)(ip + 1) * C1 + k0p);
+                    rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
+                    rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
                 }
             }
         } else {
@@ -785,14 +785,15 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                     if (!TONLY) A3[buf][part][0][ss][k0 + k] = pp[part][k];
                     A3[buf][part][1][ss][k0 + k] = pt[part][k];
                 }
-            if (ip < 3) {
-                const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
-                const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)(ip + 1) * C1 + k0;
+            if (nx < 4) {
+                const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)nx * C1 + k0;
+                const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)nx * C1 + k0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
             }
         }
-        lds_barrier();                                         // (LDS only: the next pixel's loads stay in flight)
+    };
+    auto products = [&](int ip, int buf) {
 #pragma unroll
         for (int lc = 0; lc < NL; ++lc) {
             const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
@@ -831,6 +832,23 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                 acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[lc], 0, 0, 0);
             }
         }
+    };
+    // The two waves of a SIMD (w and w + 4 = the two chunk groups) take the phases of an input pixel in opposite order: waves 0-3
+    // multiply pixel ip and then stage pixel ip + 1 into the other buffer, waves 4-7 stage first and multiply afterwards -- one
+    // partner's vector / LDS-store work runs beside the other's MFMAs instead of both reaching the matrix pipe together.
+    stage_px(0, 1);
+    if (wg == 1) __builtin_amdgcn_s_setprio(1);                // the later-dispatched half loses every issue arbitration otherwise
+    lds_barrier();                                             // (LDS only: the next pixel's loads stay in flight)
+    for (int ip = 0; ip < 4; ++ip) {
+        const int buf = ip & 1;
+        if (wg == 0) {
+            products(ip, buf);
+            if (ip < 3) stage_px(buf ^ 1, ip + 2);
+        } else {
+            if (ip < 3) stage_px(buf ^ 1, ip + 2);
+            products(ip, buf);
+        }
+        if (ip < 3) lds_barrier();
     }
 
     // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no loads in the epilogue)
