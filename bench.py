@@ -519,6 +519,17 @@ def main():
         res, prof = hot_path_step(z, dec, cfg, timers, rank if not replicas else 0, shard_world, solo)
         torch.cuda.synchronize(dev)
         latency_ms = (time.perf_counter() - t1) * 1e3
+        # beside the K-source sweep (the roofline kernel this bench is about): the assignment alone, from ONE label-carrying
+        # solve (geo_sssp_nearest_source) -- what assign_points_to_medoids runs; must give the same rows
+        from vqvae_amd.geo.geo_shortest_paths import nearest_source_device
+        srcs_ = torch.from_numpy(res["medoids"].astype(np.int32)).to(dev)
+        nearest_source_device(res["W_lcc"], srcs_)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        _, a1_, sw1_ = nearest_source_device(res["W_lcc"], srcs_)
+        torch.cuda.synchronize(dev)
+        one_solve = {"ms": (time.perf_counter() - t2) * 1e3, "sweeps": sw1_,
+                     "equals_k_source_assignment": bool(torch.equal(a1_, res["assign_batched"]))}
         if guarded:
             box = {}
 
@@ -606,7 +617,7 @@ def main():
                      "frac_counters": (traffic * launches / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and sweep_ms > 0) else None,
                      "passes_over_minimum": (traffic * launches / kernel_bytes) if (traffic and kernel_bytes) else None},
         "stages_ms": stages_ms,
-        "parity_selfcheck": {"batched_assign_equals_fused": same, "qe": res["qe"]},
+        "parity_selfcheck": {"batched_assign_equals_fused": same, "qe": res["qe"], "one_solve_assignment": one_solve},
     }
     if guarded:
         out["config"]["regions_timed"] = {"one_build_after_the_other_ms_per_build": elapsed_plain / args.steps * 1e3,

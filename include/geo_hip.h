@@ -69,6 +69,16 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
                    float *D_out, int32_t *P_out, float *dmin_out, int32_t *argmin_out,
                    void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 
+/* Nearest source per node in ONE label-carrying solve (what assign_points_to_medoids, kmeans_optimized.py:77-106, keeps of the
+ * K x N matrix): dmin_out[v] = min_s D[s][v] (float32 of the exact fp64 sum, as geo_sssp_multi returns it), argmin_out[v] = the
+ * first source row attaining it (D.argmin(axis=0)); an unreachable node gets (+inf, 0).  Exact under the conditions of the
+ * fixed-point solve (weights within 5 binades, distances below 2^40 units); otherwise status_out[0] = 1 and nothing is written:
+ * call geo_sssp_multi with dmin_out / argmin_out instead.  status_out[1] = sweeps.  Either output may be NULL. */
+size_t geo_sssp_nearest_workspace_bytes(int32_t n, int64_t nnz);
+int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n, int64_t nnz,
+                            const int32_t *sources, int32_t n_sources, float *dmin_out, int32_t *argmin_out, void *ws,
+                            size_t ws_bytes, int32_t *status_out, void *stream);
+
 /* Device time (ms, HIP events on the call's stream) spent in the relaxation sweeps of the last
  * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
  * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel,

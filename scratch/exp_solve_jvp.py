@@ -26,3 +26,10 @@ for rep in range(reps):
     layout = lib.geo_sssp_last_profile(ms.ctypes.data, l.ctypes.data)
     print(f"rep {rep}: wall {wall:.2f} ms, sweeps {int(l[0])} in {float(ms[0]):.2f} ms, layout {layout}, max dmin {float(dmin.max()):.4g}, "
           f"checksum {float(dmin.double().sum()):.9e} {int(amin.long().sum())}", flush=True)
+# the same question answered by ONE label-carrying solve (geo_sssp_nearest_source)
+from vqvae_amd.geo.geo_shortest_paths import nearest_source_device
+for rep in range(reps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d1, a1, sw = nearest_source_device(G, src)
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+    print(f"nearest-source rep {rep}: wall {wall:.2f} ms, sweeps {sw}, equal to the K-source solve: {bool(torch.equal(d1, dmin))} {bool(torch.equal(a1, amin))}", flush=True)

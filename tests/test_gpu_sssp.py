@@ -534,3 +534,81 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persiste
     np.testing.assert_array_equal(D, Do)
     np.testing.assert_array_equal(P < 0, Po < 0)
     assert np.isinf(D[:20, 3000:]).all() and np.isinf(D[20:, :3000]).all()
+
+
+def _nearest_both_ways(W, sources, unweighted=False):
+    """(dmin, argmin) from the ONE-solve nearest-source kernel and from the K-source solve, plus the layout the former took."""
+    import torch
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import nearest_source_device, sssp_multi_device
+    from vqvae_amd import _lib
+    dev = device()
+    G = DeviceCSR.from_scipy(W, dev)
+    src = torch.from_numpy(np.asarray(sources, np.int32)).to(dev)
+    lib = _lib.load()
+    status = np.zeros(4, np.int32)
+    from vqvae_amd._device import ptr, stream_ptr, workspace
+    ws = workspace(lib.geo_sssp_nearest_workspace_bytes(G.n, G.nnz), dev)
+    d1 = torch.empty(G.n, dtype=torch.float32, device=dev)
+    a1 = torch.empty(G.n, dtype=torch.int32, device=dev)
+    _lib.check(lib.geo_sssp_nearest_source(ptr(G.indptr), ptr(G.indices), ptr(None if unweighted else G.data), G.n, G.nnz,
+                                           ptr(src), int(src.numel()), ptr(d1), ptr(a1), ptr(ws), ws.numel(),
+                                           status.ctypes.data, stream_ptr()), "geo_sssp_nearest_source")
+    dn, an, _ = nearest_source_device(G, src, unweighted=unweighted)             # (falls back by itself when declined)
+    _, _, dk, ak, _ = sssp_multi_device(G, src, unweighted=unweighted, want_D=False, want_min=True)
+    if status[0] == 0:
+        np.testing.assert_array_equal(d1.cpu().numpy(), dn.cpu().numpy())
+        np.testing.assert_array_equal(a1.cpu().numpy(), an.cpu().numpy())
+    return (dn.cpu().numpy(), an.cpu().numpy()), (dk.cpu().numpy(), ak.cpu().numpy()), int(status[0]), int(status[1])
+
+
+def test_nearest_source_in_one_solve_equals_the_k_source_solve_and_the_oracle():
+    """geo_sssp_nearest_source: min_s D[s][v] and its FIRST row from one label-carrying fixed-point solve -- against the K-source
+    solve (bit for bit, ties included) on a kNN distance graph with repeated sources, the same graph unweighted and with all
+    weights equal (ties everywhere: lowest source row wins), a long-geodesics graph, two components (unreachable nodes:
+    +inf, row 0); against the oracle's matrix on the first; and declined + answered by the K-source solve when the weights
+    span too many binades."""
+    from oracle import knn as ok
+    from oracle import sssp as osp
+    r = np.random.RandomState(11)
+    W, _ = ok.build_knn_graph(latents(6000, 16, 3), k=10, sym="union")
+    W = W.tocsr().astype(np.float32)
+    src = r.choice(6000, 200, replace=False)
+    src[17] = src[3]                                            # a repeated medoid: the lower row owns the cell
+    (dn, an), (dk, ak), declined, sweeps = _nearest_both_ways(W, src)
+    assert declined == 0 and 2 <= sweeps < 200
+    np.testing.assert_array_equal(dn, dk)
+    np.testing.assert_array_equal(an, ak)
+    D = osp.dijkstra_multi_source(W, src)
+    np.testing.assert_array_equal(dn, D.min(axis=0))
+    np.testing.assert_array_equal(an, D.argmin(axis=0))
+    assert not (an == 17).any()
+    # ties everywhere
+    for Wt, unw in ((W, True), (sparse.csr_matrix((np.ones_like(W.data), W.indices, W.indptr), shape=W.shape), False)):
+        (dn, an), (dk, ak), declined, _ = _nearest_both_ways(Wt, src, unweighted=unw)
+        assert declined == 0
+        np.testing.assert_array_equal(dn, dk)
+        np.testing.assert_array_equal(an, ak)
+    # long geodesics, JVP-like weights
+    Ws, _ = ok.build_knn_graph(swiss_roll_latents(8000, 16, 2), k=8, sym="union")
+    Ws = _jvp_like_weights(Ws.tocsr().astype(np.float32), 1)
+    srcs = r.choice(8000, 64, replace=False)
+    (dn, an), (dk, ak), declined, sweeps = _nearest_both_ways(Ws, srcs)
+    assert declined == 0 and sweeps > 8
+    np.testing.assert_array_equal(dn, dk)
+    np.testing.assert_array_equal(an, ak)
+    # two components, sources in one of them only
+    Wd = sparse.block_diag((W[:3000][:, :3000], W[3000:][:, 3000:]), format="csr", dtype=np.float32)
+    (dn, an), (dk, ak), declined, _ = _nearest_both_ways(Wd, r.choice(3000, 40, replace=False))
+    np.testing.assert_array_equal(dn, dk)
+    np.testing.assert_array_equal(an, ak)
+    assert np.isinf(dn).any() and (an[np.isinf(dn)] == 0).all()
+    # weights over 12 binades: not ours -- the wrapper answers with the K-source solve
+    Ww = W.copy()
+    Ww.data = (Ww.data * np.exp2(r.randint(0, 12, Ww.nnz))).astype(np.float32)
+    Ww = Ww.maximum(Ww.T).tocsr()
+    (dn, an), (dk, ak), declined, _ = _nearest_both_ways(Ww, src)
+    assert declined == 1
+    np.testing.assert_array_equal(dn, dk)
+    np.testing.assert_array_equal(an, ak)
+

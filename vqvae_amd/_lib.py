@@ -29,6 +29,8 @@ _SIGNATURES = {
     "geo_set_option": (ctypes.c_int, [ctypes.c_char_p, i32]),
     "geo_sssp_workspace_bytes": (sz, [i32, i64, i32]),
     "geo_sssp_multi": (ctypes.c_int, [c_p, c_p, c_p, i32, i64, c_p, i32, c_p, c_p, c_p, c_p, c_p, sz, c_p, c_p]),
+    "geo_sssp_nearest_workspace_bytes": (sz, [i32, i64]),
+    "geo_sssp_nearest_source": (ctypes.c_int, [c_p, c_p, c_p, i32, i64, c_p, i32, c_p, c_p, c_p, sz, c_p, c_p]),
     "geo_sssp_last_profile": (ctypes.c_int, [c_p, c_p]),
     "geo_sssp_plan": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
     "geo_prior_attention_fwd": (ctypes.c_int, [c_p, c_p, ctypes.c_float, i32, i32, i32, i32, c_p, c_p, c_p]),

@@ -1870,6 +1870,152 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
                            ws_bytes, sweeps_out, stream_, 0);
 }
 
+// ---- nearest source per node in ONE solve ("graph Voronoi") ------------------------------------------------------------
+// assign_points_to_medoids (kmeans_optimized.py:77-106) needs only min_s D[s][v] and the first s attaining it, not the K x N
+// matrix.  With exact arithmetic (the fixed-point units of the 32-bit solve above) that pair is the fixed point of ONE
+// label-carrying relaxation: key(v) = (distance in units << 24) | source row, key(v) <- min(key(v), key(u) + (w(u,v) << 24)).
+//   distance: min_s d(s,v) = min_u (min_s d(s,u) + w) because integer addition is monotone and exact;
+//   label:    s attains the minimum at v  <=>  some tight predecessor u (d(u) + w = d(v)) has s attaining the minimum at u
+//             (exact sums: d(s,u) + w = dmin(v) = dmin(u) + w forces d(s,u) = dmin(u)), so the smallest label over the
+//             tight predecessors is the smallest source row attaining the minimum: D.argmin(axis=0)'s first-index rule.
+// K times less work than the K-source solve.  Declines (status 1) when the weights do not qualify for the exact units or a
+// distance reaches 2^40 units; the caller then runs geo_sssp_multi.
+constexpr uint64_t V_INF = ~0ull;
+constexpr int V_LABEL_BITS = 24;
+
+__global__ __launch_bounds__(256) void voronoi_init_kernel(uint64_t *__restrict__ key, int32_t n, const int32_t *__restrict__ src,
+                                                          int32_t n_sources) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = V_INF;
+    (void)src; (void)n_sources;                               // (the sources are seeded by the next launch)
+}
+
+__global__ __launch_bounds__(256) void voronoi_seed_kernel(uint64_t *__restrict__ key, const int32_t *__restrict__ src,
+                                                          int32_t n_sources) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sources) atomicMin(reinterpret_cast<unsigned long long *>(&key[src[i]]), (unsigned long long)i);   // distance 0, label i
+}
+
+// 16 lanes per node (pull): the slot's minimum over the row's entries; ONE writer per node and sweep (plain store), reads of
+// the neighbours may see this sweep's or the last sweep's value -- either is a valid upper bound, the iteration is monotone.
+__global__ __launch_bounds__(256) void voronoi_sweep_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ wunits, uint64_t *__restrict__ key,
+                                                           int32_t n, int32_t *__restrict__ changed) {
+    const int lane16 = threadIdx.x & 15;
+    const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    uint64_t best = V_INF;
+    uint64_t mine = V_INF;
+    if (v < n) {
+        mine = key[v];
+        const int32_t e0 = indptr[v], e1 = indptr[v + 1];
+        for (int32_t e = e0 + lane16; e < e1; e += 16) {
+            const uint64_t ku = key[indices[e]];
+            const uint64_t cand = ku + ((uint64_t)wunits[e] << V_LABEL_BITS);
+            if (ku != V_INF && cand < best) best = cand;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor((unsigned long long)best, off, 64);
+        best = o < best ? o : best;
+    }
+    if (v < n && lane16 == 0 && best < mine) {
+        key[v] = best;
+        *changed = 1;                                           // (idempotent flag store)
+    }
+}
+
+__global__ __launch_bounds__(256) void voronoi_out_kernel(const uint64_t *__restrict__ key, int32_t n, double unit,
+                                                         float *__restrict__ dmin, int32_t *__restrict__ argmin,
+                                                         int32_t *__restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    if (k == V_INF) {
+        if (dmin) dmin[i] = __uint_as_float(0x7f800000u);
+        if (argmin) argmin[i] = 0;                              // an all-inf column keeps row 0 (numpy argmin)
+        return;
+    }
+    const uint64_t du = k >> V_LABEL_BITS;
+    if (du >= (1ull << 39)) *overflow = 1;                      // (sums stay far below 2^40: no carry ever reached the top)
+    if (dmin) dmin[i] = (float)((double)du * unit);
+    if (argmin) argmin[i] = (int32_t)(k & ((1ull << V_LABEL_BITS) - 1));
+}
+
+extern "C" size_t geo_sssp_nearest_workspace_bytes(int32_t n, int64_t nnz) {
+    if (n <= 0 || nnz < 0) return 1024;
+    return geo::align_up((size_t)n * 8) + geo::align_up((size_t)nnz * 4) + 4096;
+}
+
+extern "C" int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
+                                       int64_t nnz, const int32_t *sources, int32_t n_sources, float *dmin_out,
+                                       int32_t *argmin_out, void *ws, size_t ws_bytes, int32_t *status_out,
+                                       void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GEO_REQUIRE(indptr && indices && sources && ws && status_out, "geo_sssp_nearest_source: null pointer");
+    GEO_REQUIRE(n > 0 && n_sources > 0, "geo_sssp_nearest_source: n=%d n_sources=%d", n, n_sources);
+    status_out[0] = 1;                                         // declined unless everything below holds
+    status_out[1] = 0;                                         // sweeps
+    if (n_sources >= (1 << V_LABEL_BITS)) return GEO_OK;
+    geo::Arena ar(ws, ws_bytes);
+    uint64_t *key = ar.take<uint64_t>((size_t)n);
+    uint32_t *wunits = ar.take<uint32_t>((size_t)(nnz > 0 ? nnz : 1));
+    uint32_t *scratch = ar.take<uint32_t>(64);
+    if (!key || !wunits || !scratch) {
+        geo::set_error("geo_sssp_nearest_source: workspace %zu too small", ws_bytes);
+        return GEO_E_WORKSPACE;
+    }
+    int shift = 0;
+    if (weights && nnz > 0) {
+        const uint32_t init[4] = {0xffffffffu, 0u, 0u, 0u};
+        uint32_t got[4];
+        GEO_HIP_CHECK(hipMemcpyAsync(scratch, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        weight_range_kernel<<<geo::grid_for(nnz, 256 * 16, 512), 256, 0, stream>>>(weights, nnz, scratch);
+        GEO_LAUNCH_CHECK();
+        GEO_HIP_CHECK(hipMemcpyAsync(got, scratch, sizeof(got), hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (got[2]) return GEO_OK;                              // negative, NaN or infinite weight: not ours
+        if (got[0] != 0xffffffffu) {
+            const int e_min = (int)(got[0] >> 23) - 127, e_max = (int)(got[1] >> 23) - 127;
+            if ((got[0] >> 23) == 0 || 24 + (e_max - e_min) > 28) return GEO_OK;    // subnormal, or more than 2^28 units per weight
+            shift = 23 - e_min;
+        }
+        // (zero weights are 0 units: exact)
+    }
+    weight_units_kernel<<<geo::grid_for(nnz > 0 ? nnz : 1, 256, 2048), 256, 0, stream>>>(weights, nnz, shift, wunits);
+    voronoi_init_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n, sources, n_sources);
+    voronoi_seed_kernel<<<geo::grid_for(n_sources, 256), 256, 0, stream>>>(key, sources, n_sources);
+    GEO_LAUNCH_CHECK();
+    int32_t *flags = reinterpret_cast<int32_t *>(scratch);     // one flag per launch of a batch
+    constexpr int BATCH = 8;
+    int32_t hflags[BATCH];
+    const unsigned grid = (unsigned)(((int64_t)n * 16 + 255) / 256);
+    int sweeps = 0;
+    bool done = false;
+    for (int round = 0; round < 4096 && !done; ++round) {
+        GEO_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(hflags), stream));
+        for (int b = 0; b < BATCH; ++b)
+            voronoi_sweep_kernel<<<grid, 256, 0, stream>>>(indptr, indices, wunits, key, n, flags + b);
+        GEO_LAUNCH_CHECK();
+        GEO_HIP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, stream));
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int b = 0; b < BATCH; ++b) {
+            ++sweeps;
+            if (hflags[b] == 0) { done = true; break; }         // a sweep that moved nothing: the fixed point
+        }
+    }
+    GEO_REQUIRE(done, "geo_sssp_nearest_source: no fixed point after %d sweeps", sweeps);
+    GEO_HIP_CHECK(hipMemsetAsync(flags, 0, 4, stream));
+    voronoi_out_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n, std::ldexp(1.0, -shift), dmin_out, argmin_out, flags);
+    GEO_LAUNCH_CHECK();
+    int32_t over = 0;
+    GEO_HIP_CHECK(hipMemcpyAsync(&over, flags, 4, hipMemcpyDeviceToHost, stream));
+    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    status_out[1] = sweeps;
+    if (!over) status_out[0] = 0;
+    return GEO_OK;
+}
+
 extern "C" int geo_sssp_plan(int32_t n, int32_t n_sources) {
     if (n <= 0 || n_sources <= 0) return GEO_E_ARG;
     const int sb = choose_sb(n, n_sources, 0);

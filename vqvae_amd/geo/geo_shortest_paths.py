@@ -72,6 +72,28 @@ def sssp_multi_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool =
     return D, P, dmin, amin, int(sweeps[0])
 
 
+def nearest_source_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool = False):
+    """(dmin f32 [n], argmin i32 [n], sweeps) of min_s D[s][v] / its first row in ONE label-carrying solve (csrc/sssp.hip,
+    geo_sssp_nearest_source) -- what D.min(axis=0) / D.argmin(axis=0) of dijkstra_multi_source's matrix give, for K times less
+    work; when the exact fixed-point units do not apply to the weights, the K-source solve answers instead."""
+    lib = _lib.load()
+    dev = G.indptr.device
+    S, n = int(sources.numel()), G.n
+    dmin = torch.empty(n, dtype=torch.float32, device=dev)
+    amin = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = workspace(lib.geo_sssp_nearest_workspace_bytes(n, G.nnz), dev)
+    status = np.zeros(4, dtype=np.int32)
+    weights = None if unweighted else G.data
+    with torch.cuda.device(dev):
+        _lib.check(lib.geo_sssp_nearest_source(ptr(G.indptr), ptr(G.indices), ptr(weights), n, G.nnz, ptr(sources), S,
+                                               ptr(dmin), ptr(amin), ptr(ws), ws.numel(), status.ctypes.data, stream_ptr()),
+                   "geo_sssp_nearest_source")
+    if status[0] == 0:
+        return dmin, amin, int(status[1])
+    _, _, dmin, amin, sweeps = sssp_multi_device(G, sources, unweighted=unweighted, want_D=False, want_min=True)
+    return dmin, amin, sweeps
+
+
 def _normalise_sources(sources, n: int) -> np.ndarray:
     src = np.asarray(sources, dtype=int).copy()
     src[src < 0] += n

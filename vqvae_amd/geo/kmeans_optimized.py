@@ -20,7 +20,7 @@ from scipy import sparse
 
 from .. import _lib
 from .._device import DeviceCSR, device, ptr, stream_ptr, workspace
-from .geo_shortest_paths import _pull_structure, ensure_valid_graph, sssp_multi_device
+from .geo_shortest_paths import nearest_source_device, _pull_structure, ensure_valid_graph, sssp_multi_device
 
 
 def _to_device_graph(W) -> DeviceCSR:
@@ -255,8 +255,10 @@ def kpp_initialization_graph(W, K: int, seed: int = 42) -> List[int]:
 
 
 def _assign_device(G: DeviceCSR, medoids: np.ndarray):
+    # nearest medoid + distance in ONE label-carrying solve (geo_sssp_nearest_source: exact fixed-point units), the K-source
+    # solve only when the weights do not qualify
     src = torch.from_numpy(np.asarray(medoids, dtype=np.int32)).to(G.indptr.device)
-    _, _, dmin, arg, _ = sssp_multi_device(G, src, want_D=False, want_min=True)
+    dmin, arg, _ = nearest_source_device(G, src)
     return dmin, arg
 
 
