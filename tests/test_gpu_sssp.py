@@ -612,3 +612,17 @@ def test_nearest_source_in_one_solve_equals_the_k_source_solve_and_the_oracle():
     np.testing.assert_array_equal(dn, dk)
     np.testing.assert_array_equal(an, ak)
 
+
+def test_quantization_error_of_an_arbitrary_assignment_takes_the_matrix():
+    """compute_quantization_error answers the nearest-medoid assignment from the one-solve path (golden cases above); any
+    other assignment must still read D[assign[v]][v] from the K-source matrix -- against the oracle."""
+    from oracle import kmedoids as okm
+    from oracle import knn as ok
+    from vqvae_amd.geo.kmeans_optimized import assign_points_to_medoids, compute_quantization_error
+    W, _ = ok.build_knn_graph(latents(1500, 8, 4), k=8, sym="union")
+    W = W.tocsr().astype(np.float32)
+    med = np.random.RandomState(2).choice(1500, 12, replace=False)
+    nearest = assign_points_to_medoids(W, med)
+    other = (nearest + 1) % 12
+    assert compute_quantization_error(W, med, nearest) == okm.compute_quantization_error(W, med, nearest)
+    assert compute_quantization_error(W, med, other) == okm.compute_quantization_error(W, med, other)

@@ -290,8 +290,13 @@ def compute_quantization_error(W, medoids: np.ndarray, assign: np.ndarray) -> fl
     G = _to_device_graph(W)
     dev = G.indptr.device
     src = torch.from_numpy(np.asarray(medoids, dtype=np.int32)).to(dev)
-    D, _, _, _, _ = sssp_multi_device(G, src, want_D=True)
     a = torch.from_numpy(np.asarray(assign, dtype=np.int64)).to(dev)
+    # the usual call hands in the nearest-medoid assignment: then D[assign[v]][v] IS the column minimum, which one
+    # label-carrying solve gives (geo_sssp_nearest_source) -- no K x N matrix; any other assignment takes the matrix
+    dmin, amin, _ = nearest_source_device(G, src)
+    if bool((amin.long() == a).all()):
+        return _qe_from(dmin.cpu().numpy())
+    D, _, _, _, _ = sssp_multi_device(G, src, want_D=True)
     picked = D.gather(0, a.view(1, -1)).view(-1)
     return _qe_from(picked.cpu().numpy())
 
