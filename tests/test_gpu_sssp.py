@@ -170,7 +170,7 @@ def test_seeded_sweep_over_graphs_sources_and_weight_ranges():
     from oracle import sssp as osp
     from oracle.synthetic import formula_weights
     from vqvae_amd._device import DeviceCSR, device
-    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
+    from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, nearest_source_device, sssp_multi_device
     from vqvae_amd import _lib
     rs = np.random.RandomState(2024)
     seen = set()
@@ -193,6 +193,10 @@ def test_seeded_sweep_over_graphs_sources_and_weight_ranges():
         _, _, dmin, arg, _ = sssp_multi_device(G, torch.from_numpy(src.astype(np.int32)).to(device()), want_D=False, want_min=True)
         np.testing.assert_array_equal(dmin.cpu().numpy(), Do.min(axis=0))
         np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
+        # the same pair from ONE label-carrying solve (declined, and answered by the K-source solve, for the wide weight ranges)
+        d1, a1, _ = nearest_source_device(G, torch.from_numpy(src.astype(np.int32)).to(device()))
+        np.testing.assert_array_equal(d1.cpu().numpy(), Do.min(axis=0), err_msg=str((case, "nearest")))
+        np.testing.assert_array_equal(a1.cpu().numpy(), Do.argmin(axis=0), err_msg=str((case, "nearest")))
     assert len(seen) >= 3, seen                                         # several kernels really answered
 
 
