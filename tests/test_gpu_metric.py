@@ -259,10 +259,14 @@ def test_weight_stationary_convt2_kernel_agrees_with_the_tile_resident_one(n_edg
     ("batch", False, 16, 1, 28, 3000, 20000, 512),      # BatchNorm in eval mode, more edges than one pass of chunks has tiles
     ("none", True, 16, 1, 28, 777, 5001, 100),          # no norm layer, ragged sizes
     ("batch", False, 64, 3, 32, 1500, 6000, 512),       # wide latents (matrix-core first layer), 192-output head
+    ("group", True, 16, 1, 28, 2000, 9000, 512),        # GroupNorm: primal statistics per latent, the tangent's per slot
+    ("group", False, 32, 3, 32, 900, 3000, 200),
+    ("batch", False, 16, 1, 28, 5000, 100, 512),        # more latents than slots: the call falls back to the per-edge-end path
 ])
 def test_per_node_primal_is_bit_identical_to_the_per_edge_end_path(norm, training, d, cout, size, n_nodes, n_edges, bs, request):
     """Decoders with fixed statistics: the primal pass runs once per LATENT (`jvp_per_node`, default on; SURVEY 2.1 K4'), the edge
-    slots carry the tangent alone and take ReLU masks / sigmoid' from their node's rows.  Same products in the same order: the
+    slots carry the tangent alone and take ReLU masks / sigmoid' from their node's rows (GroupNorm: the primal's group statistics
+    per latent, the tangent's own per slot).  Same products in the same order: the
     lengths of the edge-list entry point must equal the per-edge-end path's (option off, and the pairs entry point) bit for bit,
     and pass the usual gate of the fp64 closed form."""
     from oracle import metric as om

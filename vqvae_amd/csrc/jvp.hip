@@ -407,15 +407,16 @@ __device__ __forceinline__ void norm_relu_gn(const float4 &g, float gamma, float
 }
 
 // pre / tpre: [slot][npx][C]; out: [slot][G].  fp64 accumulation, rounded once.
+// `prim_row` (per-node primal): the primal row of slot s is pre[prim_row[s]] (its latent's row), the tangent row stays tpre[s].
 __global__ __launch_bounds__(256) void group_stats_kernel(const float *__restrict__ pre, const float *__restrict__ tpre,
                                                          int64_t n_slots, int npx, int C, int G, float eps,
-                                                         float4 *__restrict__ out) {
+                                                         float4 *__restrict__ out, const int32_t *__restrict__ prim_row = nullptr) {
     const int cpg = C / G;
     const int64_t total = n_slots * G;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(i % G);
         const int64_t slot = i / G;
-        const float *x = pre + (size_t)slot * npx * C + (size_t)g * cpg;
+        const float *x = pre + (size_t)(prim_row ? prim_row[slot] : slot) * npx * C + (size_t)g * cpg;
         const float *t = tpre + (size_t)slot * npx * C + (size_t)g * cpg;
         double sx = 0.0, sxx = 0.0, st = 0.0, sxt = 0.0;
         for (int px = 0; px < npx; ++px)
@@ -1243,6 +1244,18 @@ __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t
     }
 }
 
+// per-node primal: the latent of every slot (start side: src, end side: dst; padding slots: latent 0)
+__global__ __launch_bounds__(256) void slot_node_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                       int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
+                                                       int64_t n_slots, int32_t *__restrict__ slot_node) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per_group = (int64_t)tiles_per_group * TS;
+        const int64_t g = i / per_group, within = i % per_group;
+        const int64_t e = e_base + (g >> 1) * batch + within;
+        slot_node[i] = (within < batch && e < n_edges) ? ((g & 1) ? dst[e] : src[e]) : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------- back
 // One workgroup = BACK_TS sample slots.  LDS (dynamic): a2 / ta2 [BACK_TS][16 px][c2] after norm2 + ReLU,
 // the packed ConvT3 taps W3p [16][co][c2], and the squared tangent outputs.  A work item is
@@ -1730,10 +1743,11 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
     // 1.89 M edge ends.  One launch sequence over the latents keeps pre2 and the output sigmoids per node; the edge slots then
     // carry the tangent alone (ConvT2 and ConvT3 at half the matrix work, no primal stores), taking the ReLU masks and
     // sigmoid' from their node's rows.  Same products in the same order: lengths are bit-identical to the per-slot path
-    // (`jvp_per_node = 0`).  Train-mode BatchNorm (batch statistics change with the chunk) and GroupNorm's tangent (statistics
-    // of the tangent itself) keep the per-slot path.
+    // (`jvp_per_node = 0`).  GroupNorm's statistics are per sample, hence per latent for the primal; the tangent's own group
+    // statistics stay per slot (group_stats_kernel with the slot -> latent map).  Train-mode BatchNorm (batch statistics change
+    // with the chunk) keeps the per-slot path.
     const bool mid_all_path = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 && mid_opt != 2 && !mid_stat;
-    const bool per_node = !batch_stats && dc->norm != 2 && src && dst && pre2_node && mid_all_path && back_mfma &&
+    const bool per_node = !batch_stats && src && dst && pre2_node && mid_all_path && back_mfma &&
                           geo::options().jvp_per_node != 0;
     if (per_node) {
         const int64_t nt_node = (int64_t)(node_slots / TS);
@@ -1752,21 +1766,32 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 #undef GEO_FRONT_MFMA_N
 #undef GEO_FRONT_N
         GEO_LAUNCH_CHECK();
-#define GEO_MIDA_N(C1V)                                                                                            \
-    mid_all_kernel<C1V, false><<<(unsigned)nt_node, 512, 0, stream>>>(pre1, tpre1, k1, 0, (int)nt_node, tab, s.c2, B3,  \
-                                                                      dc->b2, pre2_node, tpre2, part2, 0, slot_valid, \
-                                                                      nullptr, 0, n_nodes, big_batch)
-        if (s.c1 == 128) GEO_MIDA_N(128);
-        else if (s.c1 == 64) GEO_MIDA_N(64);
-        else GEO_MIDA_N(32);
+        if (gs1) {
+            group_stats_kernel<<<geo::grid_for((int64_t)node_slots * 32, 256), 256, 0, stream>>>(pre1, tpre1, (int64_t)node_slots, 4,
+                                                                                                 s.c1, 32, dc->eps, gs1);
+            GEO_LAUNCH_CHECK();
+        }
+#define GEO_MIDA_N(C1V, GNV)                                                                                       \
+    mid_all_kernel<C1V, GNV><<<(unsigned)nt_node, 512, 0, stream>>>(pre1, tpre1, k1, 0, (int)nt_node, tab, s.c2, B3,    \
+                                                                    dc->b2, pre2_node, tpre2, part2, 0, slot_valid,   \
+                                                                    gs1, 0, n_nodes, big_batch)
+        if (gs1) { if (s.c1 == 128) GEO_MIDA_N(128, true); else if (s.c1 == 64) GEO_MIDA_N(64, true); else GEO_MIDA_N(32, true); }
+        else if (s.c1 == 128) GEO_MIDA_N(128, false);
+        else if (s.c1 == 64) GEO_MIDA_N(64, false);
+        else GEO_MIDA_N(32, false);
 #undef GEO_MIDA_N
         GEO_LAUNCH_CHECK();
-        if (back_nt == 1)
-            back_mfma_kernel<1, false, 2><<<(unsigned)nt_node, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, (int)nt_node, s.co,
-                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node);
-        else
-            back_mfma_kernel<6, false, 2><<<(unsigned)nt_node, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, (int)nt_node, s.co,
-                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node);
+        if (gs2) {
+            group_stats_kernel<<<geo::grid_for((int64_t)node_slots * 32, 256), 256, 0, stream>>>(pre2_node, tpre2, (int64_t)node_slots,
+                                                                                                 16, s.c2, 32, dc->eps, gs2);
+            GEO_LAUNCH_CHECK();
+        }
+#define GEO_BACK_N(NTV, GNV)                                                                                       \
+    back_mfma_kernel<NTV, GNV, 2><<<(unsigned)nt_node, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, (int)nt_node, s.co,   \
+                                                                         s.s_out, W3b, dc->b3, norms, gs2, sg_node)
+        if (back_nt == 1) { if (gs2) GEO_BACK_N(1, true); else GEO_BACK_N(1, false); }
+        else { if (gs2) GEO_BACK_N(6, true); else GEO_BACK_N(6, false); }
+#undef GEO_BACK_N
         GEO_LAUNCH_CHECK();
     }
     const int64_t total_chunks = (n_edges + batch - 1) / batch;
@@ -1825,13 +1850,14 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                                                           units, slots_tab, Bs, dc->b2, pre2, tpre2, part2,
                                                           batch_stats ? 1 : 0, e_base, n_edges, batch);
         } else if (mid_all && per_node) {
-#define GEO_MIDA_T(C1V)                                                                                            \
-    mid_all_kernel<C1V, false, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group, tab, \
-                                                                            s.c2, B3, dc->b2, pre2, tpre2, part2, 0,   \
-                                                                            slot_valid, nullptr, e_base, n_edges, batch)
-            if (s.c1 == 128) GEO_MIDA_T(128);
-            else if (s.c1 == 64) GEO_MIDA_T(64);
-            else GEO_MIDA_T(32);
+#define GEO_MIDA_T(C1V, GNV)                                                                                       \
+    mid_all_kernel<C1V, GNV, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group, tab,  \
+                                                                          s.c2, B3, dc->b2, pre2, tpre2, part2, 0,     \
+                                                                          slot_valid, gs1, e_base, n_edges, batch)
+            if (gs1) { if (s.c1 == 128) GEO_MIDA_T(128, true); else if (s.c1 == 64) GEO_MIDA_T(64, true); else GEO_MIDA_T(32, true); }
+            else if (s.c1 == 128) GEO_MIDA_T(128, false);
+            else if (s.c1 == 64) GEO_MIDA_T(64, false);
+            else GEO_MIDA_T(32, false);
 #undef GEO_MIDA_T
         } else if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
@@ -1868,7 +1894,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                                                                           const_cast<float *>(dc->rm2), const_cast<float *>(dc->rv2));
             GEO_LAUNCH_CHECK();
         }
-        if (gs2) {
+        if (gs2 && per_node) {                                  // (slot_valid is not read on this path: it carries the slot -> latent map)
+            slot_node_kernel<<<geo::grid_for(p_slots, 256), 256, 0, stream>>>(src, dst, e_base, n_edges, batch, pl.tiles_per_group,
+                                                                             p_slots, slot_valid);
+            group_stats_kernel<<<geo::grid_for(p_slots * 32, 256), 256, 0, stream>>>(pre2_node, tpre2, p_slots, 16, s.c2, 32,
+                                                                                    dc->eps, gs2, slot_valid);
+            GEO_LAUNCH_CHECK();
+        } else if (gs2) {
             group_stats_kernel<<<geo::grid_for(p_slots * 32, 256), 256, 0, stream>>>(pre2, tpre2, p_slots, 16, s.c2, 32,
                                                                                     dc->eps, gs2);
             GEO_LAUNCH_CHECK();
@@ -1877,14 +1909,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
     back_mfma_kernel<NTV, GNV><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2, tpre2, k2, batch_stats ? 1 : 0,         \
                                                                       pl.tiles_per_group, s.co, s.s_out, W3b,       \
                                                                       dc->b3, norms, gs2)
-        if (per_node && back_nt == 1)
-            back_mfma_kernel<1, false, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co,
-                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node,
-                                                                                 src, dst, e_base, n_edges, batch);
-        else if (per_node)
-            back_mfma_kernel<6, false, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co,
-                                                                                 s.s_out, W3b, dc->b3, norms, nullptr, sg_node,
-                                                                                 src, dst, e_base, n_edges, batch);
+#define GEO_BACK_T(NTV, GNV)                                                                                       \
+    back_mfma_kernel<NTV, GNV, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co, \
+                                                                         s.s_out, W3b, dc->b3, norms, gs2, sg_node, src,   \
+                                                                         dst, e_base, n_edges, batch)
+        if (per_node && back_nt == 1) { if (gs2) GEO_BACK_T(1, true); else GEO_BACK_T(1, false); }
+        else if (per_node) { if (gs2) GEO_BACK_T(6, true); else GEO_BACK_T(6, false); }
+#undef GEO_BACK_T
         else if (back_mfma && back_nt == 1) { if (gs2) GEO_BACK(1, true); else GEO_BACK(1, false); }
         else if (back_mfma) { if (gs2) GEO_BACK(6, true); else GEO_BACK(6, false); }
 #undef GEO_BACK
