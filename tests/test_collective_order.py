@@ -100,3 +100,36 @@ def test_ticket_order_puts_the_final_exchange_of_a_build_behind_the_early_ones_o
     assert o._ticket(2, early) < o._ticket(2, late)
     tickets = sorted(o._ticket(b, s) for b in range(8) for s in range(len(STAGES)))
     assert len(set(tickets)) == len(tickets)
+
+
+def test_a_failed_build_wakes_the_builds_waiting_behind_its_tickets():
+    """Build 0 fails before its first collective; build 1 is parked behind build 0's early tickets (its own ticket is larger):
+    `abort` must make it raise instead of waiting for a ticket that never comes; `finish` alone (a build that simply skipped
+    everything) must let it through."""
+    import threading
+    import time
+    from vqvae_amd.parallel import CollectiveOrder
+    for how in ("abort", "finish"):
+        o = CollectiveOrder(3, 2)
+        out = {}
+
+        def waiter():
+            try:
+                out["value"] = o.issue(1, "knn_idx", lambda: "issued")
+            except RuntimeError as e:
+                out["error"] = e
+
+        t = threading.Thread(target=waiter)
+        t.start()
+        time.sleep(0.3)
+        assert t.is_alive() and not out                        # parked: build 0 has not issued or given up anything
+        if how == "abort":
+            o.abort(ValueError("build 0 failed"))
+        else:
+            o.finish(0)
+        t.join(5)
+        assert not t.is_alive()
+        if how == "abort":
+            assert "error" in out and isinstance(out["error"].__cause__, ValueError)
+        else:
+            assert out.get("value") == "issued"
