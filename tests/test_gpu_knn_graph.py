@@ -380,6 +380,10 @@ def test_two_level_thresholds_from_200k_rows_vs_oracle_and_one_level(d, shift):
         _lib.load().geo_set_option(b"knn_filter", 1)
     np.testing.assert_array_equal(out[1][0], out[2][0])
     np.testing.assert_array_equal(out[1][1], out[2][1])
+    # a rank's share of the query rows (sharded kNN): the same rows of the full answer
+    ia, da = knn_search_device(torch.from_numpy(z).to(device()), kq, 70001, 140777)
+    np.testing.assert_array_equal(ia.cpu().numpy(), out[1][0][70001:140777])
+    np.testing.assert_array_equal(da.cpu().numpy(), out[1][1][70001:140777])
     for r0, r1 in ((0, 24), (104000, 104024), (n - 24, n)):
         io, do = _oracle_rows(z, kq, 1 if d > 15 else 0, r0, r1)
         np.testing.assert_array_equal(out[1][0][r0:r1], io)
