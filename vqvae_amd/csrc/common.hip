@@ -167,7 +167,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, void *tmp, si
 
 }  // namespace geo
 
-extern "C" int geo_version(void) { return 100; }
+extern "C" int geo_version(void) { return 103; }   // 1.0.3: + geo_sssp_nearest_source, geo_jvp_edges_workspace_bytes, geo_pam_swap_deltas, prior kernels
 extern "C" const char *geo_last_error(void) { return geo::g_err; }
 
 extern "C" int geo_set_option(const char *name, int32_t value) {
