@@ -188,6 +188,33 @@ def test_c2_every_bn_chunk_vs_fp64_and_reference_cli_sample(c2, golden):
     assert abs(float(L.astype(np.float64).sum()) / float(g["lengths_sum"]) - 1.0) < 1e-6
 
 
+def test_c2_eval_mode_per_node_primal_at_full_size(c2, request):
+    """The C2 graph's 946 059 edges with the decoder in EVAL mode (fixed BatchNorm statistics): the per-node primal path
+    (one primal pass over the 60 000 latents, tangent-only edge slots; default) against the per-edge-end path bit for bit,
+    and against the fp64 closed form (torch fp64 on the GPU) at the usual gate."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport
+    src, dst = c2["res"]["edges"]
+    dec = _decoder(c2["sd"], D, 1, c2["size"]).to(c2["dev"]).eval()
+    ex = DecoderExport(dec, c2["dev"])
+    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_per_node", 1))
+    out = {}
+    for mode in (1, 0):
+        _lib.check(_lib.load().geo_set_option(b"jvp_per_node", mode), "geo_set_option")
+        out[mode] = edge_lengths_graph_device(ex, c2["z"], src, dst, 512).cpu().numpy()
+    np.testing.assert_array_equal(out[1], out[0])
+    s_h, d_h = src.cpu().numpy(), dst.cpu().numpy()
+    ref64 = om.edge_lengths(c2["sd"], "batch", c2["size"], c2["z_h"][s_h], c2["z_h"][d_h], batch_size=512, training=False,
+                            dtype=torch.float64, device="cuda").numpy()
+    rel = np.abs(out[1] - ref64) / ref64
+    _record("c2_eval_mode_per_node_vs_fp64", {"edges": int(len(rel)), "frac_within": float(np.mean(rel <= TOL)),
+                                              "p99": float(np.quantile(rel, 0.99)), "max_rel": float(rel.max())})
+    assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
+    assert np.quantile(rel, 0.99) < 2e-6
+
+
 def test_c2_full_chain_vs_oracle_and_dense_matrix(c2):
     from oracle import kmedoids as ok
     from oracle import sssp as osp
