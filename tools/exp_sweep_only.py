@@ -1,5 +1,5 @@
 """Multi-source sweep alone on the bench c2 graph shape (distance-weighted kNN graph, 512 random sources).
-Run under rocprofv3 --kernel-trace to get per-launch durations (scratch/sweep_trace.py prints them)."""
+Run under rocprofv3 --kernel-trace to get per-launch durations (tools/sweep_trace.py prints them)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vqvae_amd import _lib
