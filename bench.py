@@ -29,7 +29,8 @@ def host_cores() -> int:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, int(os.environ.get("GEO_BENCH_CPU_THREADS", "16"))))
+    cap = os.environ.get("GEO_BENCH_CPU_THREADS")             # explicit cap only; the default is every core of the affinity mask
+    return max(1, min(avail, int(cap))) if cap else max(1, avail)
 
 
 os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))      # before numpy/torch/OpenMP start their pools
@@ -196,7 +197,9 @@ def cpu_baseline(res, z, dec, cfg, full):
                   f"(reference runs 3K-1 = {n_solves} single-thread solves)")
     total = t_knn + t_jvp + t_kmed
     return {"value": n / total, "unit": "latents/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "host_logical_cpus": os.cpu_count(), "sample": sample,
+            "host_logical_cpus": os.cpu_count(), "capped_at": os.environ.get("GEO_BENCH_CPU_THREADS"),
+            "cores_note": "kNN (OpenMP) and JVP (torch CPU) use `cores` threads = the process's affinity mask; the 3K-1 Dijkstra solves "
+                          "are single-threaded as scipy's are in the reference", "sample": sample,
             "stages_s": {"knn": round(t_knn, 3), "jvp": round(t_jvp, 3), "kmedoids": round(t_kmed, 3)}}
 
 
@@ -494,9 +497,11 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        region_prof[:] = [pr for _, _, pr, _ in done]            # per-build HIP-event sweep time measured INSIDE the timed region
         return el, [ok for _, _, _, ok in done]
 
     fallback_note = None
+    region_prof = []
     with contextlib.redirect_stdout(sys.stderr):
         for sl in range(depth):                                   # every slot warms up its own stream and workspace
             with torch.cuda.stream(slots[sl][0]):
@@ -509,6 +514,7 @@ def main():
             # after the other is timed first, the pipelined region runs under a watchdog, and the line reports the faster of
             # the two -- or the plain one, if the pipelined region does not come back.
             elapsed_plain, same_plain = timed_region(1)
+            prof_plain = list(region_prof)
         else:
             elapsed, all_same = timed_region(depth)
         # one more build, alone and instrumented (NOT part of a timed region): stage times and single-build latency
@@ -555,6 +561,7 @@ def main():
                     fallback_note = f"the region with {depth} builds in flight did not come back within {limit:.0f} s"
                 log("bench.py: " + fallback_note + "; reporting the region with one build after the other")
                 elapsed, all_same, depth = elapsed_plain, same_plain, 1
+                region_prof[:] = prof_plain
             hung = th.is_alive()
         else:
             hung = False
@@ -582,6 +589,11 @@ def main():
     per_edge, per_node = (4.0 + 8.0 / 32, 8.0) if res["sweep_kernel"] == "sweep_chunk32u_kernel" else (8.0 + 8.0 / 16, 16.0)
     kernel_bytes = res["sources_this_rank"] * (per_edge * nnz + per_node * n)
     ms_per_step = elapsed / args.steps * 1e3
+    # the same kernel INSIDE the timed region (other builds' kNN / JVP / chain kernels share the chip while it runs): mean of the
+    # per-build HIP-event sweep times that every timed build returned
+    fl_ms = [m for m, l in region_prof if l > 0]
+    in_flight_ms = sum(fl_ms) / len(fl_ms) if fl_ms else 0.0
+    in_flight_launches = (sum(l for _, l in region_prof) / len(region_prof)) if region_prof else 0
     stages_ms = {k_: v * 1e3 for k_, v in timers.items()}          # of the one instrumented build after the timed region
     sharded = res.get("sharded", {})
     if replicas:
@@ -608,6 +620,13 @@ def main():
         "latency_ms_single_build": latency_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "frac_measured_on": "one instrumented build alone, after the timed region (solo); frac_in_flight = the same kernel's "
+                                         "mean over the builds OF the timed region, other builds' kernels sharing the chip",
+                     "frac_in_flight": (algo_bytes / (in_flight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_flight_ms > 0 else None,
+                     "in_flight": {"builds": len(region_prof), "pipeline_depth": depth, "mean_sweep_ms_per_build": in_flight_ms,
+                                   "mean_launches_per_build": in_flight_launches,
+                                   "avg_launch_ms": in_flight_ms / in_flight_launches if in_flight_launches else None,
+                                   "min_sweep_ms": min(fl_ms) if fl_ms else None, "max_sweep_ms": max(fl_ms) if fl_ms else None},
                      "kernel": res["sweep_kernel"], "launches_per_step": launches,
                      "avg_launch_ms": sweep_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, launches),
@@ -627,22 +646,42 @@ def main():
     # f32-MFMA peak; stage wall time (whole stage incl. graph assembly / BN statistics), this rank's share of the work
     share = 1.0 / shard_world
     if stages_ms.get("knn"):
-        fl = 2.0 * cfg["n"] ** 2 * cfg["d"] * share
-        out["roofline_knn"] = {"bound": "fp64-valu", "achieved": fl / (stages_ms["knn"] * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": fl / (stages_ms["knn"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                               "model": "2*N^2*d flop / kNN stage time (search + symmetrise + edge list)"}
+        nn, dd = cfg["n"], cfg["d"]
+        fl64 = 2.0 * nn ** 2 * dd * share
+        t_knn = stages_ms["knn"] * 1e-3
+        filtered = nn >= (40000 if dd <= 16 else 20000 if dd <= 32 else 16384)       # csrc/knn.hip: matrix-core filter + fp64 refinement
+        if filtered:
+            # what the matrix pipe is ISSUED: every (query, corpus) pair, 3 split products (hi*hi, hi*lo, lo*hi) of
+            # v_mfma_f32_32x32x16_bf16 per 16 padded dimensions = 3 * 2 * N^2 * dp flop
+            dp = ((dd + 15) // 16) * 16
+            issued = 3.0 * 2.0 * nn ** 2 * dp * share
+            out["roofline_knn"] = {"bound": "mfma-bf16", "achieved": issued / t_knn / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": issued / t_knn / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                   "model": "issued bf16 flop of the filter scan (3 split MFMA products per pair and 16 dims) / kNN STAGE time "
+                                            "(thresholds + scan + fp64 refinement + symmetrise + edge list); the exact fp64 work rides on the VALU beside it",
+                                   "equivalent_fp64_tflops": fl64 / t_knn / 1e12,
+                                   "equivalent_model": "SURVEY 8(d): 2*N^2*d flop / stage time -- the fp64 brute-force scan this stage REPLACES, "
+                                                       f"not executed as such (fp64 vector peak {FP64_PEAK_TFLOPS} TFLOP/s); no fraction is formed from it"}
+        else:
+            out["roofline_knn"] = {"bound": "fp64-valu", "achieved": fl64 / t_knn / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": fl64 / t_knn / 1e12 / FP64_PEAK_TFLOPS,
+                                   "model": "2*N^2*d fp64 flop (exact scan: this size runs no filter) / kNN stage time (search + symmetrise + edge list)"}
     if stages_ms.get("jvp"):
         per_edge_fl = jvp_flop_per_edge(cfg["d"], cfg["cout"], cfg["size"])
-        fl = per_edge_fl * res["n_edges"] * share
-        eff = fl / (stages_ms["jvp"] * 1e-3) / 1e12
-        out["roofline_jvp"] = {"bound": "mfma-f32 (EFFECTIVE f32 flop: the products run as 6 bf16 MFMAs each)", "achieved": eff,
-                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": eff / F32_MFMA_PEAK_TFLOPS,
-                               "flop_per_edge": per_edge_fl,
-                               # matrix-pipe view of the same stage: issued bf16 flop (6 x the f32 MACs of ConvT2 + ConvT3, the
-                               # layers that run on MFMA) against the dense bf16 peak; MFMA-busy cycles are in profiles/
-                               "frac_bf16_peak": 6.0 * eff / BF16_MFMA_PEAK_TFLOPS,
-                               "model": f"{per_edge_fl / 1e6:.2f} MFLOP/edge from the decoder shape (d={cfg['d']}, {cfg['size']}-px, "
-                                        f"{cfg['cout']} ch) / JVP stage time (whole stage: first layer, BatchNorm statistics, ConvT2, head)"}
+        c0, c1, c2 = 256, 128, 64
+        pairs3 = 64 if int(cfg["size"]) == 28 else 196
+        mfma_mac = 36 * c1 * c2 + pairs3 * c2 * cfg["cout"]           # ConvT2 + ConvT3: the layers that run on the matrix pipe
+        t_jvp = stages_ms["jvp"] * 1e-3
+        issued = 6.0 * 8.0 * mfma_mac * res["n_edges"] * share         # 2 ends x (primal + tangent) x 2 flop x 6 bf16 products per f32 product
+        eff = per_edge_fl * res["n_edges"] * share / t_jvp / 1e12
+        out["roofline_jvp"] = {"bound": "mfma-bf16", "achieved": issued / t_jvp / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": issued / t_jvp / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                               "model": "issued bf16 flop: 6 MFMA products (exact 3-way bf16 split) per f32 MAC of ConvT2 + ConvT3, useful taps only "
+                                        "/ JVP STAGE time (first layer, BatchNorm statistics, ConvT2, head); MFMA-busy cycles are in profiles/",
+                               "flop_per_edge": per_edge_fl, "equivalent_f32_tflops": eff,
+                               "equivalent_model": f"{per_edge_fl / 1e6:.2f} MFLOP/edge of f32 arithmetic from the decoder shape (d={cfg['d']}, {cfg['size']}-px, "
+                                                   f"{cfg['cout']} ch) / stage time -- what an f32 implementation would execute (f32-MFMA peak "
+                                                   f"{F32_MFMA_PEAK_TFLOPS} TFLOP/s); no fraction is formed from it"}
     # multi-GPU accounting: bytes each rank RECEIVES per step in the all-gather merges, and the part of the step
     # that does not shard (the k-means++ chain + component labelling are replicated) -- the first scaling line explains itself
     E = res["n_edges"]
@@ -654,6 +693,8 @@ def main():
     serial_ms = stages_ms.get("kmedoids", 0.0) + stages_ms.get("lcc", 0.0)
     out["serial_fraction"] = {"ms_not_sharded": serial_ms, "of_single_build": serial_ms / latency_ms if latency_ms > 0 else None,
                               "amdahl_limit_8_gpus_single_build": (latency_ms / (serial_ms + (latency_ms - serial_ms) / 8.0)) if world == 1 and latency_ms > 0 else None}
+    if hung:
+        out["hang"] = True                            # the pipelined region never came back: the value above is the plain region's
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             full = args.workload in ("c1", "c2") and os.environ.get("GEO_BENCH_CPU_SAMPLE", "0") != "1"
@@ -661,9 +702,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(res, z, dec, cfg, full)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if hung:                                        # host threads parked inside the region that never came back: leave without joining them
-        sys.stderr.flush()
-        os._exit(0)
+    if hung:                                        # host threads parked inside the region that never came back: leave without joining
+        sys.stderr.flush()                          # them, and say so in the exit code (the line above carries "hang": true)
+        os._exit(3)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

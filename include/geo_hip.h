@@ -70,10 +70,15 @@ int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, const float *w
                    void *ws, size_t ws_bytes, int32_t *sweeps_out, void *stream);
 
 /* Nearest source per node in ONE label-carrying solve (what assign_points_to_medoids, kmeans_optimized.py:77-106, keeps of the
- * K x N matrix): dmin_out[v] = min_s D[s][v] (float32 of the exact fp64 sum, as geo_sssp_multi returns it), argmin_out[v] = the
- * first source row attaining it (D.argmin(axis=0)); an unreachable node gets (+inf, 0).  Exact under the conditions of the
- * fixed-point solve (weights within 5 binades, distances below 2^40 units); otherwise status_out[0] = 1 and nothing is written:
- * call geo_sssp_multi with dmin_out / argmin_out instead.  status_out[1] = sweeps.  Either output may be NULL. */
+ * K x N matrix): dmin_out[v] = min_s D[s][v] and argmin_out[v] = D.argmin(axis=0)[v] of the FLOAT32 matrix dijkstra_multi_source
+ * returns (geo_shortest_paths.py:50 casts before kmeans_optimized.py:100 compares): the lowest source row whose distance ROUNDS
+ * to the column's float32 minimum -- not necessarily the exactly nearest one.  An unreachable node gets (+inf, 0).
+ * The CSR must be symmetric (undirected graph, what the reference's callers pass): nodes whose two nearest sources round to the
+ * same float32 ("suspects") are resolved by a solve from those nodes read at the sources.
+ * status_out (host, int32 [4]): [0] = 0 answered / 1 declined (nothing usable written: call geo_sssp_multi with dmin_out /
+ * argmin_out instead), [1] = sweeps, [2] = suspect nodes found, [3] = reason when declined (1 weights outside 28 bits of their
+ * common power-of-two unit, negative or non-finite; 2 a distance reached 2^39 units; 3 more than 32 suspects; 4 n_sources >= 2^24 - 1).
+ * Either output may be NULL.  Synchronises. */
 size_t geo_sssp_nearest_workspace_bytes(int32_t n, int64_t nnz);
 int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n, int64_t nnz,
                             const int32_t *sources, int32_t n_sources, float *dmin_out, int32_t *argmin_out, void *ws,

@@ -16,7 +16,10 @@ def last_json(path):
 
 
 shutil.copy(glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)[0], f"{dst}/{tag}_c2_kernel_stats.csv")
-for name, out in (("bench.json", "c2_bench"), ("bench_under_rocprof.json", "c2_bench_under_rocprof"),
+solo = glob.glob(src + "/trace_solo/**/*kernel_stats.csv", recursive=True)
+if solo:
+    shutil.copy(solo[0], f"{dst}/{tag}_c2_solo_kernel_stats.csv")
+for name, out in (("bench_solo_under_rocprof.json", "c2_bench_solo_under_rocprof"), ("bench.json", "c2_bench"), ("bench_under_rocprof.json", "c2_bench_under_rocprof"),
                   ("bench_c3.json", "c3_bench"), ("bench_swiss.json", "swiss_bench"), ("bench_c4.json", "c4_bench"),
                   ("bench_real.json", "real_bench"), ("bench_c5cb.json", "c5cb_bench"), ("bench_c5prior.json", "c5prior_bench")):
     if os.path.exists(os.path.join(src, name)):

@@ -424,6 +424,50 @@ def test_c3_d64_knn_jvp_chain_vs_oracle(c3):
     _full_chain_vs_oracle(c3, KMED)
 
 
+def _nearest_equals_k_source(G, K, seeds, dev):
+    """Random medoid sets on a resident graph: the one-solve assignment (float32 tie rule of kmeans_optimized.py:100) against
+    the K-source solve's column argmin / minimum.  Returns what each attempt reported."""
+    from vqvae_amd.geo.geo_shortest_paths import nearest_source_device, sssp_multi_device
+    log = []
+    for seed in seeds:
+        src = torch.from_numpy(np.random.RandomState(seed).choice(G.n, K, replace=False).astype(np.int32)).to(dev)
+        info = {}
+        d1, a1, _ = nearest_source_device(G, src, info=info)
+        _, _, dk, ak, _ = sssp_multi_device(G, src, want_D=False, want_min=True)
+        assert torch.equal(a1, ak) and torch.equal(d1, dk), (seed, info, int((a1 != ak).sum()))
+        log.append(info)
+    return log
+
+
+def test_c2_one_solve_assignment_equals_k_source_argmin_with_float32_ties(c2):
+    """Round-3 review, next-round item 1(b) at C2: on the JVP-weighted 60 000-node graph, 512 and 4 096 random medoids per
+    seed; `nearest == K-source argmin` for every node, number of suspect nodes (two medoids inside one float32 rounding
+    window) recorded."""
+    G = c2["res"]["W_lcc"]
+    log512 = _nearest_equals_k_source(G, KMED, range(6), c2["dev"])
+    log4k = _nearest_equals_k_source(G, 4096, range(2), c2["dev"])
+    _record("c2_one_solve_assignment_float32_ties", {"K512": log512, "K4096": log4k})
+    assert not any(i["declined"] for i in log512 + log4k)
+
+
+def test_real_shape_960k_one_solve_assignment_equals_k_source_argmin():
+    """The same at the pipeline's real node count (SURVEY finding 7: 960 000 nodes of d=16, distance-weighted k=20 union
+    graph): about one float32 collision per call is expected here, so the suspect resolution runs on real data."""
+    from vqvae_amd._device import device, release_workspace
+    from vqvae_amd.geo.knn_graph_optimized import knn_graph_device
+    from oracle import synthetic as syn
+    dev = device()
+    z = torch.from_numpy(syn.gauss_latents(960_000, D, 3)).to(dev)
+    out = knn_graph_device(z, KNN, mode="distance", sym="union")
+    G = out[0] if isinstance(out, tuple) else out
+    log = _nearest_equals_k_source(G, KMED, range(4), dev)
+    _record("real_one_solve_assignment_float32_ties", {"n": int(G.n), "nnz": int(G.nnz), "K512": log})
+    assert not any(i["declined"] for i in log)
+    del G, z
+    release_workspace()
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------- C4 on one GPU
 def test_c4_one_gpu_1m_latents_k1024():
     """BASELINE config 4's workload on ONE GPU (the 8-GPU sharding is covered by the multi-rank tests): oracle rows

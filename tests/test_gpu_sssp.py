@@ -617,6 +617,145 @@ def test_nearest_source_in_one_solve_equals_the_k_source_solve_and_the_oracle():
     np.testing.assert_array_equal(an, ak)
 
 
+def _collision_gadget(extras, hops):
+    """A star of chains: medoid_i --(hops edges of 1.0, one of them + extras[i] * 2^-23)-- hub, plus a tail node behind the hub
+    (edge 0.5).  Exact distances hub <- medoid_i differ by multiples of 2^-23 and ROUND TO THE SAME float32 (hops in [4, 8):
+    spacing 2^-21, so +0, +1 and +2 units all give float32(hops); the tail sees hops + 0.5 likewise).  Returns (W, medoid
+    nodes, hub, tail)."""
+    m = len(extras)
+    n = m * hops + 2                                            # per chain: medoid + hops-1 inner nodes; hub; tail
+    hub, tail = n - 2, n - 1
+    rows, cols, data, meds = [], [], [], []
+    for i, ex in enumerate(extras):
+        chain = [i * hops + j for j in range(hops)] + [hub]
+        meds.append(chain[0])
+        for j in range(hops):
+            w = np.float32(1.0) + (np.float32(ex * 2.0 ** -23) if j == hops // 2 else np.float32(0))
+            rows += [chain[j], chain[j + 1]]
+            cols += [chain[j + 1], chain[j]]
+            data += [w, w]
+    rows += [hub, tail]
+    cols += [tail, hub]
+    data += [0.5, 0.5]
+    return sparse.csr_matrix((np.asarray(data, np.float32), (rows, cols)), shape=(n, n)), meds, hub, tail
+
+
+def _nearest_with_info(W, sources):
+    import torch
+    from vqvae_amd._device import DeviceCSR, device
+    from vqvae_amd.geo.geo_shortest_paths import nearest_source_device
+    info = {}
+    G = DeviceCSR.from_scipy(W, device())
+    d, a, _ = nearest_source_device(G, torch.from_numpy(np.asarray(sources, np.int32)).to(device()), info=info)
+    return d.cpu().numpy(), a.cpu().numpy(), info
+
+
+def test_nearest_source_breaks_float32_collisions_like_the_reference_nine_node_counter_example():
+    """Round-3 review, "what's weak" 1: medoid row 0 -- 1.0, 1.0, 1.0, 1 + 2^-23 -- v; medoid row 1 -- four edges of 1.0 -- v.
+    D[:, v] = [4.00000012, 4.0] in fp64, [4.0, 4.0] after the reference's float32 cast (geo_shortest_paths.py:50), so
+    D.argmin(axis=0)[v] = 0 (kmeans_optimized.py:100) although medoid 1 is exactly nearer.  Both row orders, the public API, and
+    the K-source path."""
+    from oracle import sssp as osp
+    from vqvae_amd.geo.kmeans_optimized import assign_points_to_medoids
+    rows, cols, data = [], [], []
+    def edge(a, b, w):
+        rows.extend([a, b]); cols.extend([b, a]); data.extend([w, w])
+    edge(0, 1, 1.0); edge(1, 2, 1.0); edge(2, 3, 1.0); edge(3, 8, np.float32(1.0) + np.float32(2.0 ** -23))
+    edge(4, 5, 1.0); edge(5, 6, 1.0); edge(6, 7, 1.0); edge(7, 8, 1.0)
+    W = sparse.csr_matrix((np.asarray(data, np.float32), (rows, cols)), shape=(9, 9))
+    for src, expect_v in (([0, 4], 0), ([4, 0], 0)):
+        D = osp.dijkstra_multi_source(W, src)
+        assert D.dtype == np.float32 and D[0, 8] == D[1, 8] == 4.0
+        assert D.argmin(axis=0)[8] == expect_v
+        d, a, info = _nearest_with_info(W, src)
+        assert not info["declined"] and info["suspects"] >= 1
+        np.testing.assert_array_equal(a, D.argmin(axis=0))
+        np.testing.assert_array_equal(d, D.min(axis=0))
+        np.testing.assert_array_equal(assign_points_to_medoids(W, np.asarray(src)), D.argmin(axis=0))
+        (dn, an), (dk, ak), declined, _ = _nearest_both_ways(W, src)
+        assert declined == 0
+        np.testing.assert_array_equal(an, ak)
+        np.testing.assert_array_equal(dn, dk)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_nearest_source_float32_collisions_seeded_family_equals_the_oracle_matrix(seed):
+    """A kNN distance graph with generic float32 weights plus planted collision gadgets (two- and three-medoid stars whose exact
+    distances differ by 1-2 units of 2^-23 but round to one float32; with three medoids the LOWEST row can be the exactly
+    FARTHEST of the three, i.e. outside the two keys the relaxation carries), source rows shuffled so that both row orders
+    occur: argmin / min of the oracle's float32 matrix, and the K-source solve, bit for bit; the suspects are counted."""
+    from oracle import knn as ok
+    from oracle import sssp as osp
+    r = np.random.RandomState(100 + seed)
+    Wm, _ = ok.build_knn_graph(latents(1500, 8, 20 + seed), k=8, sym="union")
+    blocks, meds, off, planted = [Wm.tocsr().astype(np.float32)], list(r.choice(1500, 24, replace=False)), 1500, 0
+    for g in range(3):
+        m = 2 + (g + seed) % 2
+        hops = int(r.randint(4, 8))
+        extras = list(r.permutation(3)[:m])                     # distinct multiples of 2^-23 within the rounding window
+        Wg, gm, hub, tail = _collision_gadget(extras, hops)
+        blocks.append(Wg)
+        meds += [off + x for x in gm]
+        planted += 2                                            # hub and tail
+        off += Wg.shape[0]
+    W = sparse.block_diag(blocks, format="csr", dtype=np.float32)
+    src = np.asarray(meds)[r.permutation(len(meds))]
+    D = osp.dijkstra_multi_source(W, src)
+    d, a, info = _nearest_with_info(W, src)
+    assert not info["declined"], info
+    assert planted <= info["suspects"] <= 32
+    np.testing.assert_array_equal(a, D.argmin(axis=0))
+    np.testing.assert_array_equal(d, D.min(axis=0))
+    (dn, an), (dk, ak), declined, _ = _nearest_both_ways(W, src)
+    np.testing.assert_array_equal(an, ak)
+    np.testing.assert_array_equal(dn, dk)
+    # the case the two carried keys alone cannot decide must occur in the family: lowest row exactly farthest of three
+    if seed == 0:
+        Wg, gm, hub, _ = _collision_gadget([2, 1, 0], 5)
+        Dg = osp.dijkstra_multi_source(Wg, gm)
+        assert Dg.argmin(axis=0)[hub] == 0
+        d3, a3, info3 = _nearest_with_info(Wg, gm)
+        assert not info3["declined"] and a3[hub] == 0 and info3["suspects"] >= 2
+        np.testing.assert_array_equal(a3, Dg.argmin(axis=0))
+
+
+def test_nearest_source_declines_when_float32_collisions_are_everywhere():
+    """Weights drawn from {1, 1 + 2^-23} on a kNN structure: distances from two hops on exceed 2^24 units and most nodes see
+    two medoids inside one float32 rounding window -> more suspects than the call resolves; it declines (reason 3) and the
+    wrapper's K-source solve gives the oracle's rows."""
+    from oracle import knn as ok
+    from oracle import sssp as osp
+    r = np.random.RandomState(5)
+    W, _ = ok.build_knn_graph(latents(2000, 8, 9), k=6, sym="union")
+    W = sparse.triu(W.tocsr(), k=1).tocsr().astype(np.float32)
+    W.data = (1.0 + r.randint(0, 2, W.nnz) * 2.0 ** -23).astype(np.float32)
+    W = (W + W.T).tocsr().astype(np.float32)
+    src = r.choice(2000, 40, replace=False)
+    D = osp.dijkstra_multi_source(W, src)
+    d, a, info = _nearest_with_info(W, src)
+    assert info["declined"] and info["reason"] == 3 and info["suspects"] > 32
+    np.testing.assert_array_equal(a, D.argmin(axis=0))
+    np.testing.assert_array_equal(d, D.min(axis=0))
+
+
+def test_nearest_source_never_wraps_on_heavy_long_paths():
+    """Advisor (round 3): intermediate upper bounds may pass 2^40 units although final distances do not.  A path of 6 000
+    edges whose weights alternate between 1 and 30 (28-bit units): the distance limit is checked before every add, the call
+    declines (reason 2) instead of wrapping, and the wrapper's answer is the oracle's."""
+    from oracle import sssp as osp
+    n = 6000
+    w = np.where(np.arange(n - 1) % 2 == 0, np.float32(1.0 + 2.0 ** -23), np.float32(30.0)).astype(np.float32)
+    rows = np.concatenate([np.arange(n - 1), np.arange(1, n)])
+    cols = np.concatenate([np.arange(1, n), np.arange(n - 1)])
+    W = sparse.csr_matrix((np.concatenate([w, w]), (rows, cols)), shape=(n, n))
+    src = [0, 5]
+    D = osp.dijkstra_multi_source(W, src)
+    d, a, info = _nearest_with_info(W, src)
+    assert info["declined"] and info["reason"] == 2, info
+    np.testing.assert_array_equal(a, D.argmin(axis=0))
+    np.testing.assert_array_equal(d, D.min(axis=0))
+
+
 def test_quantization_error_of_an_arbitrary_assignment_takes_the_matrix():
     """compute_quantization_error answers the nearest-medoid assignment from the one-solve path (golden cases above); any
     other assignment must still read D[assign[v]][v] from the K-source matrix -- against the oracle."""

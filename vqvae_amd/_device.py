@@ -2,6 +2,7 @@
 streams, libgeo_hip.so does the arithmetic.  Nothing here computes on the CPU."""
 import ctypes
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -29,6 +30,21 @@ def stream_ptr():
 
 
 _ws_cache = {}
+_ws_lock = threading.Lock()        # pipeline slots (host threads) look up / grow / release concurrently
+_slot_streams = {}
+
+
+def slot_streams(dev: torch.device, depth: int):
+    """The `depth` streams builds in flight run on -- ONE pool per device for the life of the process.  torch hands out fresh
+    `torch.cuda.Stream` objects round-robin from 32 handles per device and the workspace cache below is keyed by handle: a new
+    set of streams per pipelined call would pin one grow-only buffer (25 GB for the JVP stage at 60 000 x 16) per handle ever
+    seen (advisor, round 3).  Reusing the same streams bounds the cache at `depth` + 1 buffers."""
+    key = (dev.type, dev.index)
+    with _ws_lock:
+        pool = _slot_streams.setdefault(key, [])
+        while len(pool) < depth:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[:depth]
 
 
 def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
@@ -36,13 +52,14 @@ def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
     nbytes = int(nbytes) + 256
     # one buffer per (device, stream): builds pipelined on two streams (bench.py) must not share scratch
     key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _ws_cache.pop(key, None)
-        buf = None
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _ws_cache[key] = buf
-    return buf
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            _ws_cache.pop(key, None)
+            buf = None
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _ws_cache[key] = buf
+        return buf
 
 
 def release_workspace(above_bytes: int = 0) -> None:
@@ -51,8 +68,15 @@ def release_workspace(above_bytes: int = 0) -> None:
     scratch (25 GB at 60 000 x 16, batch 512) stays resident between builds -- measured, handing it back after the
     stage lets the smaller SSSP workspace split the block and the next build pays a fresh 25 GB allocation (+2.2 ms
     per 55 ms step).  A caller that builds one codebook and then needs the memory calls it afterwards."""
-    for key in [k for k, b in _ws_cache.items() if b.numel() > above_bytes]:
-        del _ws_cache[key]
+    with _ws_lock:
+        for key in [k for k, b in _ws_cache.items() if b.numel() > above_bytes]:
+            del _ws_cache[key]
+
+
+def workspace_buffers() -> int:
+    """Number of cached scratch buffers (tests: pipelined calls must not grow it without bound)."""
+    with _ws_lock:
+        return len(_ws_cache)
 
 
 @dataclass

@@ -1871,80 +1871,200 @@ extern "C" int geo_sssp_multi(const int32_t *indptr, const int32_t *indices, con
 }
 
 // ---- nearest source per node in ONE solve ("graph Voronoi") ------------------------------------------------------------
-// assign_points_to_medoids (kmeans_optimized.py:77-106) needs only min_s D[s][v] and the first s attaining it, not the K x N
-// matrix.  With exact arithmetic (the fixed-point units of the 32-bit solve above) that pair is the fixed point of ONE
-// label-carrying relaxation: key(v) = (distance in units << 24) | source row, key(v) <- min(key(v), key(u) + (w(u,v) << 24)).
-//   distance: min_s d(s,v) = min_u (min_s d(s,u) + w) because integer addition is monotone and exact;
-//   label:    s attains the minimum at v  <=>  some tight predecessor u (d(u) + w = d(v)) has s attaining the minimum at u
-//             (exact sums: d(s,u) + w = dmin(v) = dmin(u) + w forces d(s,u) = dmin(u)), so the smallest label over the
-//             tight predecessors is the smallest source row attaining the minimum: D.argmin(axis=0)'s first-index rule.
-// K times less work than the K-source solve.  Declines (status 1) when the weights do not qualify for the exact units or a
-// distance reaches 2^40 units; the caller then runs geo_sssp_multi.
+// assign_points_to_medoids (kmeans_optimized.py:77-106) needs of the K x N matrix only, per column, the minimum and the FIRST
+// row attaining it -- taken AFTER dijkstra_multi_source has cast the matrix to float32 (geo_shortest_paths.py:50,
+// kmeans_optimized.py:100).  In exact units (below) d(s,v) is an integer and f = float32 rounding is monotone, so the
+// reference's answer for column v is
+//     dmin(v) = f(min_s d(s,v)),      argmin(v) = the lowest row s with d(s,v) <= T(v),
+// T(v) = the largest integer that rounds to the same float32 as min_s d(s,v).  Below 2^24 units every integer is a float32,
+// T = the minimum itself and the rule is "lowest row among the exactly nearest"; above, a medoid that is farther by less than
+// half an ulp ties with the nearest one, and a lower row wins (round-3 review: a 9-node graph where the exactly-nearest
+// medoid is row 1 and the reference's code is 0).
+//
+// One label-carrying relaxation finds, per node, the TWO best (distance, row) keys with distinct rows:
+//   key = (distance in units << 24) | row;  a node's pair = the two smallest keys with distinct rows over
+//   {its own seeds} + {key(u) + (w(u,v) << 24) : u a neighbour, key in pair(u)}.
+//   Exact: the second-best source s2 of v reaches v through a neighbour u with d(s2,u) + w = d(s2,v); were s2 not among the
+//   two best of u, two other rows a, b would hold keys below (d(s2,u), s2) at u, hence (d(.,v), .) <= (d(.,u) + w, .) <
+//   (d(s2,v), s2) at v -- s2 would be third at best.  Integer sums are exact and order-independent, stored keys are lengths
+//   of real paths and only decrease, a sweep that changes nothing ends it.
+// Then: second key beyond T(v) (or absent) -> the first key's row is the answer (ties at equal distance already went to the
+// lower row).  Second key within T(v) and distances from 2^24 units on -> the node is SUSPECT: further sources may lie inside
+// the window.  Suspects are resolved exactly: the graph is undirected (contract of this entry point: symmetric CSR), so
+// d(s,v) = d(v,s): one multi-source solve FROM the suspects, read at the K medoids, float32 argmin with the lowest row on
+// ties (the rule of colmin32_kernel).  More than NEAREST_MAX_SUSPECTS suspects (graphs built from a few distinct weights
+// above 2^24 units), weights that do not fit 28 bits of the common unit, or a distance reaching 2^39 units: the call
+// declines (status 1) and the caller runs geo_sssp_multi.
+// Units: the largest power of two dividing every weight (lowest set mantissa bit over all weights), so unit weights are 1
+// and hop counts stay below 2^24; never coarser than the 2^(e_min - 23) of the 32-bit solve.
 constexpr uint64_t V_INF = ~0ull;
 constexpr int V_LABEL_BITS = 24;
+constexpr uint64_t V_LABEL_MASK = (1ull << V_LABEL_BITS) - 1;
+constexpr uint64_t V_DIST_LIMIT = 1ull << 39;
+constexpr int NEAREST_MAX_SUSPECTS = 32;
 
-__global__ __launch_bounds__(256) void voronoi_init_kernel(uint64_t *__restrict__ key, int32_t n, const int32_t *__restrict__ src,
-                                                          int32_t n_sources) {
+struct alignas(16) VPair { uint64_t k1, k2; };
+
+// lo / hi bit patterns, bad flag, and the lowest set bit of any weight as (biased exponent + trailing zeros of the 24-bit
+// mantissa): w = m * 2^(e - 150), lowest bit 2^(e - 150 + ctz(m))
+__global__ __launch_bounds__(256) void weight_range_lowbit_kernel(const float *__restrict__ w, int64_t nnz, uint32_t *__restrict__ out) {
+    uint32_t lo = 0xffffffffu, hi = 0u, bad = 0u, low = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        const uint32_t b = __float_as_uint(x);
+        if (!(x >= 0.0f) || b >= 0x7f800000u) bad = 1u;
+        else if (b != 0u) {
+            lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+            const uint32_t m = (b & 0x7fffffu) | 0x800000u;
+            const uint32_t lb = (b >> 23) + (uint32_t)(__ffs((int)m) - 1);
+            low = lb < low ? lb : low;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64), w2 = __shfl_xor(low, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; low = w2 < low ? w2 : low; bad |= __shfl_xor(bad, off, 64);
+    }
+    __shared__ uint32_t s_lo[4], s_hi[4], s_bad[4], s_low[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_bad[wave] = bad; s_low[wave] = low; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; low = s_low[k] < low ? s_low[k] : low; bad |= s_bad[k];
+        }
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+        if (bad) atomicOr(&out[2], 1u);
+        atomicMin(&out[3], low);
+    }
+}
+
+__global__ __launch_bounds__(256) void voronoi_init_kernel(VPair *__restrict__ key, int32_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) key[i] = V_INF;
-    (void)src; (void)n_sources;                               // (the sources are seeded by the next launch)
+    if (i < n) key[i] = VPair{V_INF, V_INF};
 }
 
-__global__ __launch_bounds__(256) void voronoi_seed_kernel(uint64_t *__restrict__ key, const int32_t *__restrict__ src,
-                                                          int32_t n_sources) {
+// distance 0, label i; a node listed twice keeps its two lowest rows (pass 0 settles k1, pass 1 offers the others to k2)
+__global__ __launch_bounds__(256) void voronoi_seed_kernel(VPair *__restrict__ key, const int32_t *__restrict__ src,
+                                                          int32_t n_sources, int pass) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_sources) atomicMin(reinterpret_cast<unsigned long long *>(&key[src[i]]), (unsigned long long)i);   // distance 0, label i
+    if (i >= n_sources) return;
+    VPair *p = &key[src[i]];
+    if (pass == 0) atomicMin(reinterpret_cast<unsigned long long *>(&p->k1), (unsigned long long)i);
+    else if (p->k1 != (uint64_t)i) atomicMin(reinterpret_cast<unsigned long long *>(&p->k2), (unsigned long long)i);
 }
 
-// 16 lanes per node (pull): the slot's minimum over the row's entries; ONE writer per node and sweep (plain store), reads of
-// the neighbours may see this sweep's or the last sweep's value -- either is a valid upper bound, the iteration is monotone.
+// keep the two smallest keys with distinct labels
+__device__ __forceinline__ void vpair_insert(uint64_t &b1, uint64_t &b2, uint64_t c) {
+    if (c == V_INF) return;
+    const uint64_t lc = c & V_LABEL_MASK;
+    if (lc == (b1 & V_LABEL_MASK)) { b1 = c < b1 ? c : b1; }           // (V_INF carries label 0xffffff, no source has it)
+    else if (c < b1) { b2 = b1; b1 = c; }
+    else if (lc == (b2 & V_LABEL_MASK)) { b2 = c < b2 ? c : b2; }
+    else if (c < b2) { b2 = c; }
+}
+
+// 16 lanes per node (pull): the slot's two best over the row's entries; ONE writer per node and sweep (plain stores), reads
+// of a neighbour may see this sweep's or the last sweep's keys, or one of each -- every stored key is a real path's, and
+// vpair_insert takes any mixture.
 __global__ __launch_bounds__(256) void voronoi_sweep_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                           const uint32_t *__restrict__ wunits, uint64_t *__restrict__ key,
-                                                           int32_t n, int32_t *__restrict__ changed) {
+                                                           const uint32_t *__restrict__ wunits, VPair *__restrict__ key,
+                                                           int32_t n, int32_t *__restrict__ changed, int32_t *__restrict__ overflow) {
     const int lane16 = threadIdx.x & 15;
     const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    uint64_t best = V_INF;
-    uint64_t mine = V_INF;
+    uint64_t b1 = V_INF, b2 = V_INF;
+    bool over = false;
     if (v < n) {
-        mine = key[v];
         const int32_t e0 = indptr[v], e1 = indptr[v + 1];
         for (int32_t e = e0 + lane16; e < e1; e += 16) {
-            const uint64_t ku = key[indices[e]];
-            const uint64_t cand = ku + ((uint64_t)wunits[e] << V_LABEL_BITS);
-            if (ku != V_INF && cand < best) best = cand;
+            const VPair ku = key[indices[e]];
+            const uint64_t w = (uint64_t)wunits[e] << V_LABEL_BITS;
+            if (ku.k1 != V_INF) {
+                if ((ku.k1 >> V_LABEL_BITS) >= V_DIST_LIMIT) over = true;     // (checked BEFORE the add: the sum cannot wrap)
+                else vpair_insert(b1, b2, ku.k1 + w);
+            }
+            if (ku.k2 != V_INF) {
+                if ((ku.k2 >> V_LABEL_BITS) >= V_DIST_LIMIT) over = true;
+                else vpair_insert(b1, b2, ku.k2 + w);
+            }
         }
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
-        const uint64_t o = __shfl_xor((unsigned long long)best, off, 64);
-        best = o < best ? o : best;
+        const uint64_t o1 = __shfl_xor((unsigned long long)b1, off, 64);
+        const uint64_t o2 = __shfl_xor((unsigned long long)b2, off, 64);
+        vpair_insert(b1, b2, o1);
+        vpair_insert(b1, b2, o2);
     }
-    if (v < n && lane16 == 0 && best < mine) {
-        key[v] = best;
-        *changed = 1;                                           // (idempotent flag store)
+    if (over) *overflow = 1;
+    if (v < n && lane16 == 0) {
+        const VPair mine = key[v];
+        vpair_insert(b1, b2, mine.k1);
+        vpair_insert(b1, b2, mine.k2);
+        if (b1 != mine.k1 || b2 != mine.k2) {
+            key[v] = VPair{b1, b2};
+            *changed = 1;                                       // (idempotent flag store)
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void voronoi_out_kernel(const uint64_t *__restrict__ key, int32_t n, double unit,
+// info[0] overflow, info[1] number of suspects; suspects[0 .. NEAREST_MAX_SUSPECTS) their nodes
+__global__ __launch_bounds__(256) void voronoi_out_kernel(const VPair *__restrict__ key, int32_t n, double unit,
                                                          float *__restrict__ dmin, int32_t *__restrict__ argmin,
-                                                         int32_t *__restrict__ overflow) {
+                                                         int32_t *__restrict__ info, int32_t *__restrict__ suspects) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = key[i];
-    if (k == V_INF) {
+    const VPair k = key[i];
+    if (k.k1 == V_INF) {
         if (dmin) dmin[i] = __uint_as_float(0x7f800000u);
         if (argmin) argmin[i] = 0;                              // an all-inf column keeps row 0 (numpy argmin)
         return;
     }
-    const uint64_t du = k >> V_LABEL_BITS;
-    if (du >= (1ull << 39)) *overflow = 1;                      // (sums stay far below 2^40: no carry ever reached the top)
-    if (dmin) dmin[i] = (float)((double)du * unit);
-    if (argmin) argmin[i] = (int32_t)(k & ((1ull << V_LABEL_BITS) - 1));
+    const uint64_t d1 = k.k1 >> V_LABEL_BITS;
+    if (d1 >= V_DIST_LIMIT) info[0] = 1;
+    const float f1 = (float)((double)d1 * unit);
+    if (dmin) dmin[i] = f1;
+    if (argmin) argmin[i] = (int32_t)(k.k1 & V_LABEL_MASK);
+    if (k.k2 != V_INF && d1 >= (1ull << 24)) {
+        const uint64_t d2 = k.k2 >> V_LABEL_BITS;
+        if ((float)((double)d2 * unit) == f1) {                 // the second source rounds to the same float32
+            const int32_t slot = atomicAdd(&info[1], 1);
+            if (slot < NEAREST_MAX_SUSPECTS) suspects[slot] = (int32_t)i;
+        }
+    }
+}
+
+// one wave per suspect: argmin over the K medoids of float32 d(suspect, medoid) = d(medoid, suspect), lowest row on ties
+__global__ __launch_bounds__(64) void voronoi_resolve_kernel(const float *__restrict__ D, int32_t n, const int32_t *__restrict__ suspects,
+                                                            const int32_t *__restrict__ src, int32_t n_sources,
+                                                            float *__restrict__ dmin, int32_t *__restrict__ argmin) {
+    const int lane = threadIdx.x;
+    const float *row = D + (size_t)blockIdx.x * n;
+    float best = __int_as_float(0x7f800000);
+    int32_t barg = 0x7fffffff;
+    for (int32_t j = lane; j < n_sources; j += 64) {
+        const float val = row[src[j]];
+        if (val < best) { best = val; barg = j; }               // (rows ascend per lane: strict < keeps the lowest)
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int32_t oi = __shfl_xor(barg, off, 64);
+        if (ov < best || (ov == best && oi < barg)) { best = ov; barg = oi; }
+    }
+    if (lane == 0) {
+        const int32_t v = suspects[blockIdx.x];
+        if (argmin) argmin[v] = barg;
+        if (dmin) dmin[v] = best;                               // (equal to what the relaxation wrote: f is monotone)
+    }
 }
 
 extern "C" size_t geo_sssp_nearest_workspace_bytes(int32_t n, int64_t nnz) {
     if (n <= 0 || nnz < 0) return 1024;
-    return geo::align_up((size_t)n * 8) + geo::align_up((size_t)nnz * 4) + 4096;
+    return geo::align_up((size_t)n * sizeof(VPair)) + geo::align_up((size_t)nnz * 4) + 4096 +
+           geo::align_up((size_t)NEAREST_MAX_SUSPECTS * n * sizeof(float)) +
+           geo_sssp_workspace_bytes(n, nnz, NEAREST_MAX_SUSPECTS) + 256;
 }
 
 extern "C" int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *indices, const float *weights, int32_t n,
@@ -1956,63 +2076,88 @@ extern "C" int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *ind
     GEO_REQUIRE(n > 0 && n_sources > 0, "geo_sssp_nearest_source: n=%d n_sources=%d", n, n_sources);
     status_out[0] = 1;                                         // declined unless everything below holds
     status_out[1] = 0;                                         // sweeps
-    if (n_sources >= (1 << V_LABEL_BITS)) return GEO_OK;
+    status_out[2] = 0;                                         // suspect nodes (float32 collisions) found
+    status_out[3] = 0;                                         // why declined: 1 weights, 2 distance limit, 3 too many suspects, 4 K
+    if (n_sources >= (1 << V_LABEL_BITS) - 1) { status_out[3] = 4; return GEO_OK; }
     geo::Arena ar(ws, ws_bytes);
-    uint64_t *key = ar.take<uint64_t>((size_t)n);
+    VPair *key = ar.take<VPair>((size_t)n);
     uint32_t *wunits = ar.take<uint32_t>((size_t)(nnz > 0 ? nnz : 1));
-    uint32_t *scratch = ar.take<uint32_t>(64);
-    if (!key || !wunits || !scratch) {
+    uint32_t *scratch = ar.take<uint32_t>(128);
+    float *Dsus = ar.take<float>((size_t)NEAREST_MAX_SUSPECTS * n);
+    const size_t multi_bytes_needed = geo_sssp_workspace_bytes(n, nnz, NEAREST_MAX_SUSPECTS);
+    char *multi_ws = ar.take<char>(multi_bytes_needed);
+    if (!key || !wunits || !scratch || !Dsus || !multi_ws) {
         geo::set_error("geo_sssp_nearest_source: workspace %zu too small", ws_bytes);
         return GEO_E_WORKSPACE;
     }
     int shift = 0;
     if (weights && nnz > 0) {
-        const uint32_t init[4] = {0xffffffffu, 0u, 0u, 0u};
+        const uint32_t init[4] = {0xffffffffu, 0u, 0u, 0xffffffffu};
         uint32_t got[4];
         GEO_HIP_CHECK(hipMemcpyAsync(scratch, init, sizeof(init), hipMemcpyHostToDevice, stream));
-        weight_range_kernel<<<geo::grid_for(nnz, 256 * 16, 512), 256, 0, stream>>>(weights, nnz, scratch);
+        weight_range_lowbit_kernel<<<geo::grid_for(nnz, 256 * 16, 512), 256, 0, stream>>>(weights, nnz, scratch);
         GEO_LAUNCH_CHECK();
         GEO_HIP_CHECK(hipMemcpyAsync(got, scratch, sizeof(got), hipMemcpyDeviceToHost, stream));
         GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        status_out[3] = 1;
         if (got[2]) return GEO_OK;                              // negative, NaN or infinite weight: not ours
         if (got[0] != 0xffffffffu) {
-            const int e_min = (int)(got[0] >> 23) - 127, e_max = (int)(got[1] >> 23) - 127;
-            if ((got[0] >> 23) == 0 || 24 + (e_max - e_min) > 28) return GEO_OK;    // subnormal, or more than 2^28 units per weight
-            shift = 23 - e_min;
+            if ((got[0] >> 23) == 0) return GEO_OK;             // subnormal weights
+            const int e_max = (int)(got[1] >> 23) - 127;
+            const int low = (int)got[3] - 150;                  // every weight is a multiple of 2^low
+            if (e_max + 1 - low > 28) return GEO_OK;            // a weight of 2^28 units or more
+            shift = -low;
         }
+        status_out[3] = 0;
         // (zero weights are 0 units: exact)
     }
     weight_units_kernel<<<geo::grid_for(nnz > 0 ? nnz : 1, 256, 2048), 256, 0, stream>>>(weights, nnz, shift, wunits);
-    voronoi_init_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n, sources, n_sources);
-    voronoi_seed_kernel<<<geo::grid_for(n_sources, 256), 256, 0, stream>>>(key, sources, n_sources);
+    voronoi_init_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n);
+    voronoi_seed_kernel<<<geo::grid_for(n_sources, 256), 256, 0, stream>>>(key, sources, n_sources, 0);
+    voronoi_seed_kernel<<<geo::grid_for(n_sources, 256), 256, 0, stream>>>(key, sources, n_sources, 1);
     GEO_LAUNCH_CHECK();
-    int32_t *flags = reinterpret_cast<int32_t *>(scratch);     // one flag per launch of a batch
+    int32_t *flags = reinterpret_cast<int32_t *>(scratch);     // [0..7] one flag per launch of a batch, [8] overflow
+    int32_t *info = flags + 16;                                 // [0] overflow at the end, [1] suspects
+    int32_t *suspects = flags + 32;                             // NEAREST_MAX_SUSPECTS nodes
     constexpr int BATCH = 8;
-    int32_t hflags[BATCH];
+    int32_t hflags[BATCH + 1];
     const unsigned grid = (unsigned)(((int64_t)n * 16 + 255) / 256);
     int sweeps = 0;
     bool done = false;
     for (int round = 0; round < 4096 && !done; ++round) {
         GEO_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(hflags), stream));
         for (int b = 0; b < BATCH; ++b)
-            voronoi_sweep_kernel<<<grid, 256, 0, stream>>>(indptr, indices, wunits, key, n, flags + b);
+            voronoi_sweep_kernel<<<grid, 256, 0, stream>>>(indptr, indices, wunits, key, n, flags + b, flags + BATCH);
         GEO_LAUNCH_CHECK();
         GEO_HIP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, stream));
         GEO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (hflags[BATCH]) { status_out[3] = 2; status_out[1] = sweeps + BATCH; return GEO_OK; }   // an upper bound reached 2^39 units
         for (int b = 0; b < BATCH; ++b) {
             ++sweeps;
             if (hflags[b] == 0) { done = true; break; }         // a sweep that moved nothing: the fixed point
         }
     }
     GEO_REQUIRE(done, "geo_sssp_nearest_source: no fixed point after %d sweeps", sweeps);
-    GEO_HIP_CHECK(hipMemsetAsync(flags, 0, 4, stream));
-    voronoi_out_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n, std::ldexp(1.0, -shift), dmin_out, argmin_out, flags);
-    GEO_LAUNCH_CHECK();
-    int32_t over = 0;
-    GEO_HIP_CHECK(hipMemcpyAsync(&over, flags, 4, hipMemcpyDeviceToHost, stream));
-    GEO_HIP_CHECK(hipStreamSynchronize(stream));
     status_out[1] = sweeps;
-    if (!over) status_out[0] = 0;
+    GEO_HIP_CHECK(hipMemsetAsync(info, 0, 8, stream));
+    voronoi_out_kernel<<<geo::grid_for(n, 256), 256, 0, stream>>>(key, n, std::ldexp(1.0, -shift), dmin_out, argmin_out, info, suspects);
+    GEO_LAUNCH_CHECK();
+    int32_t hinfo[2] = {0, 0};
+    GEO_HIP_CHECK(hipMemcpyAsync(hinfo, info, 8, hipMemcpyDeviceToHost, stream));
+    GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    status_out[2] = hinfo[1];
+    if (hinfo[0]) { status_out[3] = 2; return GEO_OK; }
+    if (hinfo[1] > NEAREST_MAX_SUSPECTS) { status_out[3] = 3; return GEO_OK; }
+    if (hinfo[1] > 0 && argmin_out) {
+        // d(suspect, .) rows: same weights, same exact sums, same float32 cast as the K x N matrix's column entries
+        if (int rc = sssp_multi_impl(indptr, indices, weights, n, nnz, suspects, hinfo[1], Dsus, nullptr, nullptr, nullptr,
+                                     multi_ws, multi_bytes_needed, nullptr, stream_, 0))
+            return rc;
+        voronoi_resolve_kernel<<<(unsigned)hinfo[1], 64, 0, stream>>>(Dsus, n, suspects, sources, n_sources, dmin_out, argmin_out);
+        GEO_LAUNCH_CHECK();
+        GEO_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    status_out[0] = 0;
     return GEO_OK;
 }
 

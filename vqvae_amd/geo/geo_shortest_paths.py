@@ -72,10 +72,12 @@ def sssp_multi_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool =
     return D, P, dmin, amin, int(sweeps[0])
 
 
-def nearest_source_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool = False):
-    """(dmin f32 [n], argmin i32 [n], sweeps) of min_s D[s][v] / its first row in ONE label-carrying solve (csrc/sssp.hip,
-    geo_sssp_nearest_source) -- what D.min(axis=0) / D.argmin(axis=0) of dijkstra_multi_source's matrix give, for K times less
-    work; when the exact fixed-point units do not apply to the weights, the K-source solve answers instead."""
+def nearest_source_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bool = False, info: Optional[dict] = None):
+    """(dmin f32 [n], argmin i32 [n], sweeps): D.min(axis=0) / D.argmin(axis=0) of dijkstra_multi_source's FLOAT32 matrix
+    (geo_shortest_paths.py:50, kmeans_optimized.py:100: the lowest row whose distance rounds to the column minimum) from ONE
+    label-carrying solve (csrc/sssp.hip, geo_sssp_nearest_source) -- K times less work than the matrix.  G must be symmetric.
+    When the call declines (weights outside the exact units, too many float32 collisions) the K-source solve answers instead.
+    `info`, if given, receives declined / reason / suspects / sweeps of the one-solve attempt."""
     lib = _lib.load()
     dev = G.indptr.device
     S, n = int(sources.numel()), G.n
@@ -88,6 +90,8 @@ def nearest_source_device(G: DeviceCSR, sources: torch.Tensor, *, unweighted: bo
         _lib.check(lib.geo_sssp_nearest_source(ptr(G.indptr), ptr(G.indices), ptr(weights), n, G.nnz, ptr(sources), S,
                                                ptr(dmin), ptr(amin), ptr(ws), ws.numel(), status.ctypes.data, stream_ptr()),
                    "geo_sssp_nearest_source")
+    if info is not None:
+        info.update(declined=bool(status[0]), reason=int(status[3]), suspects=int(status[2]), sweeps=int(status[1]))
     if status[0] == 0:
         return dmin, amin, int(status[1])
     _, _, dmin, amin, sweeps = sssp_multi_device(G, sources, unweighted=unweighted, want_D=False, want_min=True)

@@ -16,6 +16,8 @@ from typing import Callable, List, Optional
 
 import torch
 
+from ._device import slot_streams
+
 
 def run_pipelined(fn: Callable[[int, int], object], n_items: int, depth: int, device: torch.device,
                   streams: Optional[List[torch.cuda.Stream]] = None) -> list:
@@ -28,7 +30,7 @@ def run_pipelined(fn: Callable[[int, int], object], n_items: int, depth: int, de
             results[i] = fn(i, 0)
         return results
     depth = min(depth, n_items)
-    streams = streams or [torch.cuda.Stream(device=device) for _ in range(depth)]
+    streams = streams or slot_streams(device, depth)             # one pool per device: bounded workspace cache
     lock, cursor, errors = threading.Lock(), [0], []
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(device))              # work queued before the call is visible to every slot
