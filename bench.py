@@ -134,7 +134,7 @@ def hot_path_step(z, dec, cfg, timers, rank, world, group=None):
         ms_, launches_ = np.zeros(1, np.float64), np.zeros(1, np.int32)
         layout = _lib.load().geo_sssp_last_profile(ms_.ctypes.data, launches_.ctypes.data)
         prof["ms"], prof["launches"], prof["sources"] = float(ms_[0]), int(launches_[0]), s1 - s0
-        prof["kernel"] = ("push_persistent_kernel" if layout >= 5000 else "push_sweep_kernel" if layout >= 4000 else "sweep_chunk32u_kernel" if layout >= 2000
+        prof["kernel"] = ("push_sweep_kernel" if layout >= 4000 else "sweep_chunk32u_kernel" if layout >= 2000
                           else "sweep_chunk16_kernel" if layout >= 1000
                           else f"sweep_multi_kernel<{layout}>")
         return dmin_, arg_

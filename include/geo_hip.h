@@ -88,9 +88,7 @@ int geo_sssp_nearest_source(const int32_t *indptr, const int32_t *indices, const
  * geo_sssp_multi call, and how many sweep kernels it launched.  Used by bench.py's roofline.
  * Returns the layout that call used: sources per batch (16 or 64), +1000 for the chunked 16-source kernel,
  * 2032 for the exact 32-bit fixed-point kernel (32 sources per row), 4016 for the near-far push solve
- * (long geodesics: sources ordered along landmark distances, 16 per batch, delta-stepping buckets) with one launch per
- * sweep, 5016 for the same solve run to its end inside ONE launch by a team of workgroups per XCD (then
- * *sweep_launches = 1 and *sweep_ms is that launch). */
+ * (long geodesics: sources ordered along landmark distances, 16 per batch, delta-stepping buckets; one launch per sweep). */
 int geo_sssp_last_profile(double *sweep_ms, int32_t *sweep_launches);
 
 /* The layout geo_sssp_multi would START with for a graph of n nodes and n_sources sources (host arithmetic only, no GPU

@@ -26,11 +26,14 @@ def _config(tmp, mode):
 def test_legacy_builder_artefacts_equal_reference(golden, tmp_path, mode):
     from oracle import synthetic as syn
     from vqvae_amd.training.build_riemannian_codebook_legacy import build_and_save
-    from vqvae_amd.vae import VAE
+    from vqvae_amd.vae import Decoder
     g = golden("legacy_riemannian")
     tmp = str(tmp_path)
-    vae = VAE(**LEGACY_VAE)
-    torch.save({"model_state_dict": syn.seeded_state_dict(vae.state_dict(), 21), "epoch": 0}, os.path.join(tmp, "best.pt"))
+    # a reference checkpoint holds encoder.* and decoder.* entries; the builder reads the decoder's only.  (seeded_state_dict
+    # fills the keys in sorted order, "decoder." first: the same decoder weights the fixture was generated with)
+    template = {"decoder." + k: v for k, v in Decoder(1, (128, 64, 32), 16, 28, "none").state_dict().items()}
+    template["encoder.fc_mu.weight"] = torch.zeros(16, 2048)
+    torch.save({"model_state_dict": syn.seeded_state_dict(template, 21), "epoch": 0}, os.path.join(tmp, "best.pt"))
     torch.save(torch.from_numpy(syn.gauss_latents(600, 16, 22)), os.path.join(tmp, "z.pt"))
     np.random.seed(123)                                   # the subset is drawn with numpy's global generator
     out = build_and_save(_config(tmp, mode))

@@ -222,39 +222,6 @@ def test_wide_latents_matrix_core_front_equals_the_vector_kernel(d, norm, reques
     assert (rel <= TOL).mean() >= 0.999, (rel <= TOL).mean()
 
 
-@pytest.mark.parametrize("n_edges,bs,norm,training", [(5000, 512, "batch", True), (1777, 100, "batch", True),
-                                                       (3000, 512, "batch", False), (2048, 512, "none", True)])
-def test_weight_stationary_convt2_kernel_agrees_with_the_tile_resident_one(n_edges, bs, norm, training, request):
-    """`jvp_mid = 4` (GEO_JVP_MID=s): the ConvT2 kernel that keeps a unit of the weight matrix in registers and streams the
-    tiles past it (experimental, slower than the default so far -- DESIGN.md section 7).  Same arithmetic per product, other
-    summation order over k: lengths within float32 rounding of the default kernel's (ragged last chunk, more BatchNorm
-    groups than XCDs, eval mode, no norm), and within the usual gate of the fp64 closed form."""
-    from oracle import metric as om
-    from vqvae_amd import _lib
-    from vqvae_amd._device import device
-    from vqvae_amd.geo.riemannian_metric import edge_lengths_riemannian
-    from vqvae_amd.spatial_decoder import SpatialDecoder
-    sd = om.make_decoder_state(5, 16, 1, norm_type=norm)
-    dec = SpatialDecoder(1, (256, 128, 64), 16, 28, norm)
-    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    dec = dec.to(device())
-    dec = dec.train() if training else dec.eval()
-    r = np.random.RandomState(n_edges)
-    zs = r.randn(n_edges, 16).astype(np.float32)
-    ze = (zs + 0.3 * r.randn(n_edges, 16)).astype(np.float32)
-    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_mid", 0))
-    out = {}
-    for mid in (0, 4):
-        _lib.check(_lib.load().geo_set_option(b"jvp_mid", mid), "geo_set_option")
-        out[mid] = edge_lengths_riemannian(dec, torch.from_numpy(zs), torch.from_numpy(ze), bs).cpu().numpy()
-    ref64 = om.edge_lengths(sd, norm, 28, zs, ze, bs, training, dtype=torch.float64).numpy()
-    for mid in (0, 4):
-        rel = np.abs(out[mid] - ref64) / np.abs(ref64)
-        assert (rel <= TOL).mean() >= 0.999, (mid, (rel <= TOL).mean())
-    close = np.abs(out[0] - out[4]) <= 2e-6 * np.abs(out[0])
-    assert close.mean() >= 0.999, close.mean()               # (a ReLU at float32 rounding distance from zero may flip)
-
-
 @pytest.mark.parametrize("norm,training,d,cout,size,n_nodes,n_edges,bs", [
     ("batch", False, 16, 1, 28, 3000, 20000, 512),      # BatchNorm in eval mode, more edges than one pass of chunks has tiles
     ("none", True, 16, 1, 28, 777, 5001, 100),          # no norm layer, ragged sizes

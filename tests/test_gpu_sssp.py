@@ -436,7 +436,7 @@ def _set_options(request, **opts):
     from vqvae_amd import _lib
     lib = _lib.load()
     defaults = {"sssp_sb": -1, "sssp_push": 1, "sssp_delta": 8, "sssp_u32": 1, "sssp_group": 1, "sssp_push_blocks": 64,
-                "sssp_push_persistent": 0, "sssp_order": 0}
+                "sssp_order": 0}
     for name, value in opts.items():
         _lib.check(lib.geo_set_option(name.encode(), int(value)), "geo_set_option")
         request.addfinalizer(lambda name=name: lib.geo_set_option(name.encode(), defaults[name]))
@@ -484,13 +484,13 @@ def test_long_geodesics_with_wide_weights_take_the_near_far_push_solve(request):
     np.testing.assert_array_equal(arg.cpu().numpy(), Do.argmin(axis=0))
 
 
-@pytest.mark.parametrize("delta,persistent,order", [(1, 1, 1), (4, 1, 2), (1000000, 1, 1), (4, 0, 1), (1, 0, 0), (8, 0, 0), (8, 0, 2)])
-def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persistent, order, request):
+@pytest.mark.parametrize("delta,order", [(1, 1), (4, 2), (1000000, 1), (4, 1), (1, 0), (8, 0), (8, 2)])
+def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, order, request):
     """`sssp_push=2` + 16-source batches send EVERY call with more than 16 sources through the push solve, whatever the
     graph: Gaussian clouds and swiss rolls, one binade of weights or eleven, unweighted, a disconnected graph (inf
     columns, idle batches), duplicate and padded sources, for a narrow bucket (delta = 1 mean weight: many release
-    sweeps), the default and an infinite one (plain push label correcting); with all sweeps in ONE launch (a team of
-    workgroups per XCD, layout 5016) and with one launch per sweep (4016).  All equal the oracle bit for bit."""
+    sweeps), the default and an infinite one (plain push label correcting), for the three source orders (layout 4016).  All
+    equal the oracle bit for bit."""
     import torch
     from oracle import knn as okn
     from oracle import sssp as osp
@@ -498,11 +498,9 @@ def test_near_far_push_solve_forced_on_every_graph_equals_oracle(delta, persiste
     from vqvae_amd import _lib
     from vqvae_amd._device import DeviceCSR, device
     from vqvae_amd.geo.geo_shortest_paths import dijkstra_multi_source, sssp_multi_device
-    _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta, sssp_push_persistent=persistent, sssp_order=order,
+    _set_options(request, sssp_sb=16, sssp_push=2, sssp_delta=delta, sssp_order=order,
                  sssp_group=2)                                  # group 2: the sources are always ordered first (cells / landmarks)
-    # persistent: 5016 when the XCD teams ran; 4016 when the kernel declined (a block found itself on another XCD than
-    # blockIdx % 8, or a team did not assemble) and the call was answered by one launch per sweep -- both are valid
-    layouts = (5016, 4016) if persistent else (4016,)
+    layouts = (4016,)
     rs = np.random.RandomState(77)
     cases = [(3000, 6, 17, False, 0), (9000, 4, 33, True, 1), (15000, 10, 70, False, 2), (12000, 6, 130, True, 2),
              (6000, 4, 40, True, 0), (3000, 4, 130, True, 3)]

@@ -21,7 +21,6 @@ const OptionName kOptionNames[] = {
     {"sssp_order", "GEO_SSSP_ORDER", &Options::sssp_order},
     {"sssp_delta", "GEO_SSSP_DELTA", &Options::sssp_delta},
     {"sssp_push_blocks", "GEO_SSSP_PUSH_BLOCKS", &Options::sssp_push_blocks},
-    {"sssp_push_persistent", "GEO_SSSP_PUSH_PERSISTENT", &Options::sssp_push_persistent},
     {"knn_filter", "GEO_KNN_FILTER", &Options::knn_filter},
     {"kpp_grid", "GEO_KPP_GRID", &Options::kpp_grid},
     {"kpp_profile", "GEO_KPP_PROFILE", &Options::kpp_profile},
@@ -35,7 +34,7 @@ Options from_environment() {
     for (const OptionName &e : kOptionNames) {
         const char *v = getenv(e.env);
         if (!v) continue;
-        if (e.field == &Options::jvp_mid) o.jvp_mid = v[0] == 'f' ? 1 : (v[0] == 'c' ? 2 : (v[0] == 'a' ? 3 : (v[0] == 's' ? 4 : atoi(v))));
+        if (e.field == &Options::jvp_mid) o.jvp_mid = v[0] == 'f' ? 1 : (v[0] == 'c' ? 2 : (v[0] == 'a' ? 3 : atoi(v)));
         else o.*(e.field) = atoi(v);
     }
     return o;

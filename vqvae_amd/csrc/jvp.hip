@@ -890,350 +890,6 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     }
 }
 
-// ---- ConvT2 with the weights held in registers ("stationary"; dec_channels[1:] = 128, 64) -------------------------
-// mid_all_kernel re-reads 2 MB of weight fragments from the L2 for every 32-sample tile: a fragment feeds only the 64 rows
-// (32 primal + 32 tangent) of one tile, and those loads sit inside the MFMA stream (-2.9 ms of 16.5 when removed).  Here the
-// roles are turned round: a workgroup keeps the fragments of ONE unit of the weight matrix in registers for the whole
-// launch (96 registers per wave, 196 KB per workgroup) and the tiles stream past it.  Units (two 128 x 128 blocks each):
-//   kind 0  an edge pair  : 2 input pixels -> 2 output pixels (128 columns); waves = 4 column tiles x 2 halves of k
-//   kind 1  a centre pixel: 4 input pixels -> 1 output pixel  ( 64 columns); waves = 2 column tiles x 4 quarters of k
-//   kind 2  the corners   : input pixel p -> corner p only    ( 64 columns each), flushed after every input pixel
-// = 4 + 4 + 1 units, 18 block products per tile (mid_all: 20, the corner chunks are half zeros).  The price is staging:
-// every unit stages the input pixels it needs itself (28 pixel stagings per tile instead of 4), so the two waves of a SIMD
-// run the phases of an input pixel in opposite order -- one stages the next pixel (VALU, LDS writes) while the other
-// multiplies the current one (MFMA, LDS reads) -- and the raw pre-activations are re-read from the L2: workgroup ->
-// (XCD = blockIdx % 8, slot = blockIdx / 8), an XCD walks the tiles of the BatchNorm groups g = x (mod 8) with all nine
-// units (3 workgroups per kind-0 unit, 4 per kind-1/2 unit: these stage four pixels per tile), so that a tile's
-// pre-activations come from HBM once and from that XCD's L2 afterwards.  The partial sums of the k slices meet in LDS.
-constexpr int N_UNITS = 9;
-struct UnitTable { int kind[N_UNITS]; int ipix[N_UNITS][4]; int opix[N_UNITS][4]; };
-struct SlotTable { unsigned char unit[32], rank[32], count[32]; };
-
-// Bs[unit][wave 0..3][fragment][lane][8] bf16: fragment = (phase * 3 + part) * KSL + k step of the wave's slice
-__global__ __launch_bounds__(256) void pack_stat_kernel(const float *__restrict__ w2, int c1, int c2, UnitTable ut,
-                                                       unsigned short *__restrict__ Bs) {
-    const int KS = c1 / 16;
-    const size_t nf_all = (size_t)6 * KS;                          // fragments per wave: phases x 3 parts x k steps of its slice
-    const size_t total = (size_t)N_UNITS * 4 * nf_all * 512;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const int f = (int)((i >> 9) % nf_all), w = (int)((i / (512 * nf_all)) % 4), u = (int)(i / (512 * nf_all * 4));
-        const int kind = ut.kind[u];
-        const int ksl_n = kind == 0 ? KS : KS / 2;
-        const int ct = kind == 0 ? w : (w & 1), sl = kind == 0 ? 0 : (w >> 1);
-        const int ksl = f % ksl_n, part = (f / ksl_n) % 3, ph = f / (ksl_n * 3);
-        const int k = (sl * ksl_n + ksl) * 16 + (lane >> 5) * 8 + j;
-        const int colu = ct * 32 + (lane & 31);
-        const int co = colu % c2;
-        const int op = kind == 0 ? ut.opix[u][colu / c2] : (kind == 1 ? ut.opix[u][0] : ut.opix[u][ph]);
-        const int ip = ut.ipix[u][ph];
-        const int ky = (op >> 2) + 1 - 2 * (ip >> 1), kx = (op & 3) + 1 - 2 * (ip & 1);
-        float v = 0.0f;
-        if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = w2[(((size_t)k * c2 + co) * 4 + ky) * 4 + kx];
-        unsigned short p[3];
-        split3(v, p[0], p[1], p[2]);
-        Bs[i] = p[part];
-    }
-}
-
-#ifdef GEO_STAT_PROF
-__device__ unsigned long long g_stat_prof[256 * 8 * 8];
-#define GEO_PT(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#else
-#define GEO_PT(v)
-#endif
-
-extern __shared__ __attribute__((aligned(16))) unsigned char stat_lds[];   // A3 (double buffered) | R
-
-// One wave per SIMD (256 threads, up to 512 registers per lane: 192 of them hold the unit's weight fragments).  A phase =
-// one input pixel: the wave multiplies the staged block of the pixel (LDS buffer ph & 1) and, between the MFMAs of each
-// k step, stages its share of the NEXT pixel (8 of the 32 samples; lane = channel pair) into the other buffer; the raw
-// pre-activations of the pixel after that and of the one after that are on their way from the L2 meanwhile (two register
-// buffers).  kind 0: wave = 32-column tile, all of k; kinds 1 / 2: wave = (column tile, half of k), halves summed in LDS.
-template <int C1, int KIND>
-__device__ __forceinline__ void mid_stat_body(const float *__restrict__ pre1, const float *__restrict__ tpre1,
-                                              const NormConst *__restrict__ consts1, int consts_per_group, int tpg,
-                                              int n_groups, const UnitTable &ut, int unit, int x, int rank, int count,
-                                              const unsigned short *__restrict__ Bs, const float *__restrict__ b2,
-                                              float *__restrict__ pre2, float *__restrict__ tpre2,
-                                              double *__restrict__ partial2, int want_stats, int64_t e_base,
-                                              int64_t n_edges, int batch) {
-    static_assert(C1 == 128, "one lane stages a channel pair: 64 lanes x 2");
-    constexpr int LDK = C1 + 8, KS = C1 / 16;
-    constexpr int NPH = KIND == 0 ? 2 : 4, NSL = KIND == 0 ? 1 : 2, KSL = KS / NSL;
-    constexpr int SPW = TS / 4, SPS = SPW / KSL;               // samples staged per wave and phase / per k step
-    constexpr int c2 = 64, n1 = 4 * C1, n2 = 16 * c2;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    unsigned short *A3 = reinterpret_cast<unsigned short *>(stat_lds);
-    float *R = reinterpret_cast<float *>(stat_lds + (size_t)2 * 3 * 2 * TS * LDK * 2);
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address parts)
-    const int ct = KIND == 0 ? w : (w & 1), sl = KIND == 0 ? 0 : (w >> 1);
-    const int r = lane & 31, h = lane >> 5;
-
-    bf16x8 b[NPH][3][KSL];
-    {
-        const unsigned short *bp = Bs + ((size_t)(unit * 4 + w) * (NPH * 3 * KSL)) * 512 + (size_t)lane * 8;
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-            for (int part = 0; part < 3; ++part)
-#pragma unroll
-                for (int ksl = 0; ksl < KSL; ++ksl)
-                    b[ph][part][ksl] = *reinterpret_cast<const bf16x8 *>(bp + (size_t)((ph * 3 + part) * KSL + ksl) * 512);
-    }
-    auto a3 = [&](int buf, int part, int strm, int row, int k) -> unsigned short * {
-        return A3 + ((size_t)(((buf * 3 + part) * 2 + strm) * TS + row)) * LDK + k;
-    };
-    auto tile_of = [&](int j, int *tile) -> bool {             // j-th tile of this XCD's groups g = x (mod 8)
-        const int g = (j / tpg) * 8 + x;
-        if (g >= n_groups) return false;
-        *tile = g * tpg + j % tpg;
-        return true;
-    };
-    // this tile and the two after it (the pipeline looks three phases ahead); past the end the last tile is repeated:
-    // its addresses are valid, what is staged from them is never multiplied
-    int j = rank, T0 = 0, T1 = 0, T2 = 0;
-    if (!tile_of(j, &T0)) return;
-    bool has_next = tile_of(j + count, &T1);
-    if (!has_next) T1 = T0;
-    if (!tile_of(j + 2 * count, &T2)) T2 = T1;
-
-    const int k0 = 2 * lane, s0 = SPW * w;
-    f32x2 rp[2][SPW], rt[2][SPW];                              // two raw buffers, indexed by phase parity (constants after unrolling)
-    NormConst kA, kB, nA, nB;                                  // constants of the lane's two channels: this tile's, the next tile's
-    auto load_consts = [&](int t, NormConst *qa, NormConst *qb) {
-        const NormConst *kp = consts1 + (size_t)(consts_per_group ? t / tpg : 0) * C1 + k0;
-        *qa = kp[0];
-        *qb = kp[1];
-    };
-    auto tile_at = [&](int idx) -> int { return idx == 0 ? T0 : (idx == 1 ? T1 : T2); };
-
-    const int colu = ct * 32 + r, co = colu & (c2 - 1);
-    const float bias = b2[co];
-
-#define GEO_FETCH(RB, I, KPH)                                                                                        \
-    {                                                                                                                \
-        const size_t fs_ = (size_t)tile_at((KPH) / NPH) * TS + s0 + (I);                                             \
-        const int fp_ = ut.ipix[unit][(KPH) % NPH];                                                                  \
-        rp[RB][I] = *reinterpret_cast<const f32x2 *>(pre1 + fs_ * n1 + (size_t)fp_ * C1 + k0);                       \
-        rt[RB][I] = *reinterpret_cast<const f32x2 *>(tpre1 + fs_ * n1 + (size_t)fp_ * C1 + k0);                      \
-    }
-#define GEO_STAGE(BUF, RB, I, QA, QB)                                                                                \
-    {                                                                                                                \
-        float a0_, t0_, a1_, t1_;                                                                                    \
-        norm_relu(QA, rp[RB][I].x, rt[RB][I].x, &a0_, &t0_);                                                         \
-        norm_relu(QB, rp[RB][I].y, rt[RB][I].y, &a1_, &t1_);                                                         \
-        unsigned wa_[3], wt_[3];                                                                                     \
-        split3_pair(a0_, a1_, wa_[0], wa_[1], wa_[2]);                                                               \
-        split3_pair(t0_, t1_, wt_[0], wt_[1], wt_[2]);                                                               \
-        _Pragma("unroll") for (int part_ = 0; part_ < 3; ++part_) {                                                  \
-            *reinterpret_cast<unsigned *>(a3(BUF, part_, 0, s0 + (I), k0)) = wa_[part_];                             \
-            *reinterpret_cast<unsigned *>(a3(BUF, part_, 1, s0 + (I), k0)) = wt_[part_];                             \
-        }                                                                                                            \
-    }
-
-    load_consts(T0, &kA, &kB);
-    nA = kA; nB = kB;
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) GEO_FETCH(0, i, 0)
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) GEO_FETCH(1, i, 1)
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) GEO_STAGE(0, 0, i, kA, kB)
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) GEO_FETCH(0, i, 2)
-    lds_barrier();
-
-    f32x16 accp, acct;
-#ifdef GEO_STAT_PROF
-    unsigned long long pM = 0, pB = 0, pE = 0, pN = 0;
-    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    for (;;) {
-        const int tile = T0;
-        const size_t slot0 = (size_t)tile * TS;
-        if (KIND != 2) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
-        }
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-            const int buf = ph & 1;                            // (NPH is even: phase parity carries over from tile to tile)
-            const bool last = ph == NPH - 1;
-            if (KIND == 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { accp[i] = 0.f; acct[i] = 0.f; }
-            }
-            GEO_PT(t0);
-            if (ph == NPH - 2) load_consts(T1, &nA, &nB);      // used by the last phase's staging (the next tile's first pixel)
-            // One wave per SIMD has no partner to cover its waits: the instruction stream itself is the schedule.  Per k
-            // step: 12 MFMAs; behind each one a fixed piece of the other work -- one of the six LDS reads of the NEXT step's
-            // A fragments, or a quarter of a sample's staging (normalise / split primal / split tangent / stores and the
-            // refill of its raw registers) -- and a scheduling barrier, so that the compiler keeps the pieces there.
-            const NormConst &qA = last ? nA : kA, &qB = last ? nB : kB;
-            constexpr int RB = 0; (void)RB;
-            bf16x8 ap[3], at[3], apn[3], atn[3];
-            {
-                const int ks0 = sl * KSL;
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    ap[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 0, r, ks0 * 16 + h * 8));
-                    at[part] = *reinterpret_cast<const bf16x8 *>(a3(buf, part, 1, r, ks0 * 16 + h * 8));
-                }
-            }
-#pragma unroll
-            for (int ksl = 0; ksl < KSL; ++ksl) {
-                const int ksn = sl * KSL + (ksl + 1 < KSL ? ksl + 1 : ksl);      // (the last step re-reads its own: keeps the stream uniform)
-                const int rb = (ph + 1) & 1;
-                float sa0[SPS], st0[SPS], sa1[SPS], st1[SPS];
-                unsigned wa[SPS][3], wt[SPS][3];
-#define GEO_NEXT_A(PART, STRM)                                                                                      \
-    { if (STRM == 0) apn[PART] = *reinterpret_cast<const bf16x8 *>(a3(buf, PART, 0, r, ksn * 16 + h * 8));          \
-      else atn[PART] = *reinterpret_cast<const bf16x8 *>(a3(buf, PART, 1, r, ksn * 16 + h * 8)); }
-#define GEO_NORM(U)                                                                                                  \
-    { const int i_ = ksl * SPS + (U);                                                                                \
-      norm_relu(qA, rp[rb][i_].x, rt[rb][i_].x, &sa0[U], &st0[U]);                                                   \
-      norm_relu(qB, rp[rb][i_].y, rt[rb][i_].y, &sa1[U], &st1[U]); }
-#define GEO_SPLIT_A(U) split3_pair(sa0[U], sa1[U], wa[U][0], wa[U][1], wa[U][2]);
-#define GEO_SPLIT_T(U) split3_pair(st0[U], st1[U], wt[U][0], wt[U][1], wt[U][2]);
-#define GEO_WRITE(U, STRM)                                                                                           \
-    { const int i_ = ksl * SPS + (U);                                                                                \
-      _Pragma("unroll") for (int part_ = 0; part_ < 3; ++part_)                                                      \
-          *reinterpret_cast<unsigned *>(a3(buf ^ 1, part_, STRM, s0 + i_, k0)) = STRM == 0 ? wa[U][part_] : wt[U][part_]; }
-#define GEO_REFILL(U) { const int i_ = ksl * SPS + (U); GEO_FETCH(rb, i_, ph + 3) }
-#define GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[ph][0][ksl], accp, 0, 0, 0);
-                GEO_NEXT_A(0, 0) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[ph][0][ksl], acct, 0, 0, 0);
-                GEO_NEXT_A(0, 1) GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][2][ksl], accp, 0, 0, 0);
-                GEO_NORM(0) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][2][ksl], acct, 0, 0, 0);
-                GEO_NEXT_A(1, 0) if (SPS > 1) GEO_SPLIT_A(0) GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][1][ksl], accp, 0, 0, 0);
-                GEO_NEXT_A(1, 1) if (SPS > 1) GEO_SPLIT_T(0) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][1][ksl], acct, 0, 0, 0);
-                if (SPS == 1) GEO_SPLIT_A(0) else { GEO_WRITE(0, 0) GEO_WRITE(0, 1) } GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[ph][0][ksl], accp, 0, 0, 0);
-                GEO_NEXT_A(2, 0) if (SPS > 1) GEO_REFILL(0) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[ph][0][ksl], acct, 0, 0, 0);
-                GEO_NEXT_A(2, 1) GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][1][ksl], accp, 0, 0, 0);
-                if (SPS == 1) GEO_SPLIT_T(0) else GEO_NORM(SPS - 1) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][1][ksl], acct, 0, 0, 0);
-                if (SPS == 1) GEO_WRITE(0, 0) else GEO_SPLIT_A(SPS - 1) GEO_SLOT_END
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[ph][0][ksl], accp, 0, 0, 0);
-                if (SPS == 1) GEO_WRITE(0, 1) else GEO_SPLIT_T(SPS - 1) GEO_SLOT_END
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[ph][0][ksl], acct, 0, 0, 0);
-                if (SPS == 1) GEO_REFILL(0) else { GEO_WRITE(SPS - 1, 0) GEO_WRITE(SPS - 1, 1) GEO_REFILL(SPS - 1) } GEO_SLOT_END
-                // the pieces are pure values to the compiler and land wherever it likes: pin the pattern instead -- per slot one
-                // MFMA, then an LDS read (first six slots), a handful of vector instructions, an LDS store / a global load
-#pragma unroll
-                for (int slot = 0; slot < 12; ++slot) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-                    if (slot < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, SPS == 1 ? 5 : 9, 0);   // VALU
-                    if (slot >= 6) __builtin_amdgcn_sched_group_barrier(0x200, SPS, 0); // DS write
-                    if (slot >= 10) __builtin_amdgcn_sched_group_barrier(0x020, SPS, 0);// VMEM read
-                }
-#undef GEO_NEXT_A
-#undef GEO_NORM
-#undef GEO_SPLIT_A
-#undef GEO_SPLIT_T
-#undef GEO_WRITE
-#undef GEO_REFILL
-#undef GEO_SLOT_END
-#pragma unroll
-                for (int part = 0; part < 3; ++part) { ap[part] = apn[part]; at[part] = atn[part]; }
-            }
-            GEO_PT(t1);
-            const bool flush = KIND == 2 || last;
-            if (NSL > 1 && flush && sl > 0) {                  // partial sums of the second half of k -> LDS
-                float *rq = R + (size_t)(ct * 32) * 64 + lane;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { rq[q * 64] = accp[q]; rq[(16 + q) * 64] = acct[q]; }
-            }
-            lds_barrier();
-            GEO_PT(t2);
-            if (flush) {
-                if (NSL > 1 && sl == 0) {
-                    const float *rq = R + (size_t)(ct * 32) * 64 + lane;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { accp[q] += rq[q * 64]; acct[q] += rq[(16 + q) * 64]; }
-                }
-                if (KIND == 2) lds_barrier();                  // the corners flush every phase: R is rewritten one phase later
-                if (sl == 0) {
-                    const int op = KIND == 0 ? ut.opix[unit][colu >> 6] : (KIND == 1 ? ut.opix[unit][0] : ut.opix[unit][ph]);
-                    // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no load)
-                    const int g = tile / tpg;
-                    int64_t cnt = n_edges - (e_base + (int64_t)(g >> 1) * batch);
-                    if (cnt > batch) cnt = batch;
-                    const int n_valid = (int)cnt - (tile - g * tpg) * TS;
-                    double sx = 0, sxx = 0, st_ = 0, sxt = 0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-                        const float xv = accp[q] + bias, tv = acct[q];
-                        pre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = xv;
-                        tpre2[(slot0 + row) * n2 + (size_t)op * c2 + co] = tv;
-                        if (row < n_valid) { sx += xv; sxx += (double)xv * xv; st_ += tv; sxt += (double)xv * tv; }
-                    }
-                    if (want_stats) {
-                        sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
-                        st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
-                        if (lane < 32) {
-                            double *p = partial2 + ((size_t)tile * n2 + (size_t)op * c2 + co) * 4;
-                            p[0] = sx; p[1] = sxx; p[2] = st_; p[3] = sxt;
-                        }
-                    }
-                }
-            }
-#ifdef GEO_STAT_PROF
-            { GEO_PT(t3); pM += t1 - t0; pB += t2 - t1; pE += t3 - t2; pN += 1; }
-#endif
-        }
-        if (!has_next) break;
-        j += count;
-        T0 = T1;
-        {
-            int t1_ = 0;
-            has_next = tile_of(j + count, &t1_);
-            T1 = has_next ? t1_ : T0;
-            if (!tile_of(j + 2 * count, &T2)) T2 = T1;
-        }
-        kA = nA; kB = nB;
-    }
-#undef GEO_FETCH
-#undef GEO_STAGE
-#ifdef GEO_STAT_PROF
-    if (lane == 0) {
-        unsigned long long *o = g_stat_prof + ((size_t)blockIdx.x * 8 + w) * 8;
-        o[0] = 0; o[1] = pM; o[2] = pB; o[3] = pE; o[4] = pN; o[5] = __builtin_amdgcn_s_memtime() - pc0; o[6] = KIND;
-        o[7] = __builtin_amdgcn_s_memrealtime() - pr0;
-    }
-#endif
-}
-
-template <int C1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void mid_stat_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
-                     const NormConst *__restrict__ consts1, int consts_per_group, int tiles_per_group, int n_groups,
-                     UnitTable ut, SlotTable st, const unsigned short *__restrict__ Bs, const float *__restrict__ b2,
-                     float *__restrict__ pre2, float *__restrict__ tpre2, double *__restrict__ partial2, int want_stats,
-                     int64_t e_base, int64_t n_edges, int batch) {
-    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
-    if (s >= 32) return;
-    const int unit = st.unit[s], rank = st.rank[s], count = st.count[s];
-    const int kind = ut.kind[unit];
-#define GEO_STAT_BODY(KINDV)                                                                                       \
-    mid_stat_body<C1, KINDV>(pre1, tpre1, consts1, consts_per_group, tiles_per_group, n_groups, ut, unit, x, rank,   \
-                             count, Bs, b2, pre2, tpre2, partial2, want_stats, e_base, n_edges, batch)
-    if (kind == 0) GEO_STAT_BODY(0);
-    else if (kind == 1) GEO_STAT_BODY(1);
-    else GEO_STAT_BODY(2);
-#undef GEO_STAT_BODY
-}
-
 __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
                                                         int64_t n_slots, int32_t *__restrict__ slot_valid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1551,36 +1207,6 @@ void make_chunks(const Shape &s, ChunkTable *t) {
     }
 }
 
-// Units of the weight-stationary ConvT2 kernel (4x4 output pixels from 2x2 input pixels, k4 s2 p1): an output pixel is
-// fed by the input pixels (iy, ix) with 0 <= oy + 1 - 2 iy < 4 and the same in x: corners by one, edge pixels by two (the
-// two edge pixels of a side share them), the four centre pixels by all four.
-void make_units(UnitTable *t, SlotTable *st) {
-    int u = 0;
-    static const int edge[4][2][2] = {{{0, 1}, {0, 2}}, {{3, 1}, {3, 2}}, {{1, 0}, {2, 0}}, {{1, 3}, {2, 3}}};
-    for (int e = 0; e < 4; ++e, ++u) {
-        t->kind[u] = 0;
-        int n = 0;
-        for (int ip = 0; ip < 4; ++ip) {
-            const int ky = edge[e][0][0] + 1 - 2 * (ip >> 1), kx = edge[e][0][1] + 1 - 2 * (ip & 1);
-            if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) t->ipix[u][n++] = ip;
-        }
-        for (int i = n; i < 4; ++i) t->ipix[u][i] = 0;
-        for (int lo = 0; lo < 4; ++lo) t->opix[u][lo] = edge[e][lo & 1][0] * 4 + edge[e][lo & 1][1];
-    }
-    for (int c = 0; c < 4; ++c, ++u) {
-        t->kind[u] = 1;
-        for (int ip = 0; ip < 4; ++ip) { t->ipix[u][ip] = ip; t->opix[u][ip] = (1 + (c >> 1)) * 4 + 1 + (c & 1); }
-    }
-    t->kind[u] = 2;
-    for (int ip = 0; ip < 4; ++ip) { t->ipix[u][ip] = ip; t->opix[u][ip] = 12 * (ip >> 1) + 3 * (ip & 1); }
-    // 32 workgroup slots per XCD: three per edge unit, four per centre / corner unit (those stage four pixels per tile)
-    int cnt[N_UNITS], s = 0;
-    for (int i = 0; i < N_UNITS; ++i) cnt[i] = t->kind[i] == 0 ? 3 : 4;
-    for (int r = 0; r < 4; ++r)
-        for (int i = 0; i < N_UNITS; ++i)
-            if (r < cnt[i] && s < 32) { st->unit[s] = (unsigned char)i; st->rank[s] = (unsigned char)r; st->count[s] = (unsigned char)cnt[i]; ++s; }
-}
-
 struct Plan {
     Shape sh;
     int batch, tiles_per_group, slots_per_group;
@@ -1615,7 +1241,6 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
     b += geo::align_up((size_t)s.d * s.n1 * 4) + geo::align_up((size_t)s.n1 * 4);          // M01, b01
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 4);                   // B2p
     b += geo::align_up((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 2 * 3);               // B3 (bf16 x 3)
-    b += geo::align_up((size_t)N_UNITS * 4 * 6 * (s.c1 / 16 + 1) * 512 * 2);                // Bs (register-resident units)
     b += geo::align_up((size_t)16 * s.co * s.c2 * 4);                                       // W3p
     b += geo::align_up((size_t)16 * s.c2 * 192 * 3 * 2);                                    // W3b (bf16 x 3)
     b += 2 * geo::align_up(slots * s.n1 * 4) + 2 * geo::align_up(slots * s.n2 * 4);         // pre1,tpre1,pre2,tpre2
@@ -1656,7 +1281,6 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
     float *b01 = ar.take<float>((size_t)s.n1);
     float *B2p = ar.take<float>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC);
     unsigned short *B3 = ar.take<unsigned short>((size_t)s.n_chunks * MAX_BLOCKS * s.c1 * NC * 3);
-    unsigned short *Bs = ar.take<unsigned short>((size_t)N_UNITS * 4 * 6 * (s.c1 / 16 + 1) * 512);
     float *W3p = ar.take<float>((size_t)16 * s.co * s.c2);
     unsigned short *W3b = ar.take<unsigned short>((size_t)16 * s.c2 * 192 * 3);
     float *pre1 = ar.take<float>(slots * s.n1), *tpre1 = ar.take<float>(slots * s.n1);
@@ -1708,20 +1332,6 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
             B2p, s.c1, s.n_chunks, B3);
         GEO_LAUNCH_CHECK();
     }
-    // weight-stationary ConvT2 (the shipped decoder widths), experimental: GEO_JVP_MID=s; default = the tile-resident mid_all_kernel
-    const bool mid_stat = mid_split && mid_opt == 4 && dc->norm != 2 && s.c1 == 128 && s.c2 == 64 && s.n_chunks == 8 && s.opix_per_chunk == 2;
-    UnitTable units;
-    SlotTable slots_tab;
-    const size_t stat_lds_bytes = (size_t)2 * 3 * 2 * TS * (128 + 8) * 2 + (size_t)2 * 32 * 64 * 4;
-    if (mid_stat) {
-        GEO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_stat_kernel<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stat_lds_bytes));
-        make_units(&units, &slots_tab);
-        pack_stat_kernel<<<geo::grid_for((int64_t)N_UNITS * 4 * 6 * (s.c1 / 16) * 512, 256), 256, 0, stream>>>(
-            dc->w2, s.c1, s.c2, units, Bs);
-        GEO_LAUNCH_CHECK();
-    }
-
     if (dc->norm == 2) {
         // the GroupNorm path exists for the 32-group layouts of the matrix-core kernels (reference default decoder)
         GEO_REQUIRE(dc->groups1 == 32 && dc->groups2 == 32 && s.c2 == 64 && back_mfma && mid_split && s.n_chunks == 8 &&
@@ -1746,7 +1356,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
     // (`jvp_per_node = 0`).  GroupNorm's statistics are per sample, hence per latent for the primal; the tangent's own group
     // statistics stay per slot (group_stats_kernel with the slot -> latent map).  Train-mode BatchNorm (batch statistics change
     // with the chunk) keeps the per-slot path.
-    const bool mid_all_path = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 && mid_opt != 2 && !mid_stat;
+    const bool mid_all_path = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 && mid_opt != 2;
     const bool per_node = !batch_stats && src && dst && pre2_node && mid_all_path && back_mfma &&
                           geo::options().jvp_per_node != 0;
     if (per_node) {
@@ -1844,12 +1454,8 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                                                     s.opix_per_chunk, s.c2, B3, dc->b2, pre2, tpre2, part2,        \
                                                     batch_stats ? 1 : 0, slot_valid)
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
-                             mid_opt != 2 && !mid_stat;
-        if (mid_stat) {
-            mid_stat_kernel<128><<<256, 256, stat_lds_bytes, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_groups,
-                                                          units, slots_tab, Bs, dc->b2, pre2, tpre2, part2,
-                                                          batch_stats ? 1 : 0, e_base, n_edges, batch);
-        } else if (mid_all && per_node) {
+                             mid_opt != 2;
+        if (mid_all && per_node) {
 #define GEO_MIDA_T(C1V, GNV)                                                                                       \
     mid_all_kernel<C1V, GNV, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group, tab,  \
                                                                           s.c2, B3, dc->b2, pre2, tpre2, part2, 0,     \
@@ -1931,12 +1537,6 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 }
 
 }  // namespace
-
-#ifdef GEO_STAT_PROF
-extern "C" int geo_debug_stat_prof(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stat_prof), sizeof(unsigned long long) * 256 * 8 * 8);
-}
-#endif
 
 extern "C" size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size) {
     Plan pl;

@@ -736,78 +736,6 @@ __global__ __launch_bounds__(256) void push_sweep_kernel(const int32_t *__restri
     if (busy && xb == 0 && threadIdx.x == 0) st.active[sweep % 3] = 1;
 }
 
-// ---- ALL sweeps in ONE launch: a team of workgroups per XCD ----------------------------------------------------------
-// Kernel boundaries drop the L2 (the XCDs' L2s are not coherent with each other, so every launch starts cold): with one
-// launch per sweep each of the ~9 dependent loads / atomics of a sweep is served by the Infinity Cache, ~45 us per sweep
-// however little work it has (measured; scratch/micro/atom.hip), times several hundred sweeps.  Here the batches of an XCD
-// (batch % 8 == XCD) are solved to the end by the workgroups resident on THAT XCD: they share its L2, where returning
-// atomics take ~370 ns, so a sweep boundary is one team barrier on an L2 counter and the rows of the moving fronts stay
-// cached from sweep to sweep.  Teams of different XCDs never synchronise (batches are independent).
-//   * blockIdx % 8 is ASSUMED to be the XCD (round-robin dispatch); every block checks it against the XCC_ID hardware
-//     register and raises ctl.abort otherwise -- the host then solves the call with one launch per sweep;
-//   * the barrier spins with a bound: a team member that does not arrive (workgroups of the grid not co-resident) also
-//     ends in ctl.abort, never in a hang; every wave reaches the exit.
-//   * team members see each other's plain stores through the shared L2; a sweep starts with an agent-scope acquire
-//     (invalidates the CU's L1).  Stale L1 lines inside a sweep can only hold OLDER (larger) distances, which cost work,
-//     not correctness -- the same argument as for one launch per sweep.
-struct TeamCtl {
-    int32_t *bar;        // 8 counters, 32 ints apart
-    int32_t *abort;      // 0 ok, 1 barrier timeout, 2 block not on its XCD
-    int32_t *sweeps;     // [8] sweeps each XCD's team ran
-};
-
-__device__ __forceinline__ unsigned xcc_id() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xfu;     // HW_REG_XCC_ID (20), bits 3:0
-#else
-    return 0u;
-#endif
-}
-
-template <bool WEIGHTED>
-__global__ __launch_bounds__(512) void push_persistent_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                             const float *__restrict__ weights, int32_t n, int32_t nb,
-                                                             double *dist, PushState st, double delta, TeamCtl ctl, int32_t team,
-                                                             int32_t max_sweeps, int32_t spin_limit) {
-    __shared__ int32_t sh_go;
-    const int xcd = blockIdx.x & 7, member = blockIdx.x >> 3;
-    const int groups8 = (nb + 7) >> 3;
-    if (threadIdx.x == 0 && xcc_id() != (unsigned)xcd) __hip_atomic_store(ctl.abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int32_t *bar = ctl.bar + xcd * 32;
-    int32_t sweep = 0;
-    for (; sweep < max_sweeps; ++sweep) {
-        bool busy = false;
-        for (int g = 0; g < groups8; ++g) {
-            const int b = xcd + 8 * g;
-            if (b < nb)
-                busy |= push_batch_sweep<WEIGHTED, 32>(indptr, indices, weights, n, nb, b, member, team, dist, st, delta, sweep);
-        }
-        // ---- team barrier: stores of this block are in the L2 (write-through L1, waited for) before it signs in
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int32_t target = (sweep + 1) * team;
-            int32_t go = 1, spins = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (__hip_atomic_load(ctl.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { go = 0; break; }
-                if (++spins > spin_limit) {
-                    __hip_atomic_store(ctl.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    go = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (__hip_atomic_load(ctl.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) go = 0;
-            sh_go = go;
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (!sh_go || !busy) break;                              // `busy` is the same in every block of the team
-    }
-    if (member == 0 && threadIdx.x == 0) ctl.sweeps[xcd] = sweep + 1;
-}
-
 __global__ __launch_bounds__(256) void push_init_kernel(const int32_t *__restrict__ src_pad, int32_t n, int32_t nb, PushState st,
                                                        double delta) {
     // one block per batch: near list = the chunks of the batch's distinct sources, everything else empty
@@ -1250,7 +1178,6 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     uint32_t *wunits = nullptr, *wrange = nullptr;           // 32-bit fixed-point weights / their range
     int32_t *chunk_cnt = nullptr, *row_order = nullptr;
     PushState push{};
-    int32_t *team_ctl = nullptr;
     uint32_t *cell_adj = nullptr;
     double *wsum = nullptr;
     const geo::Options &opt = geo::options();
@@ -1294,7 +1221,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         push.far_slot = ar.take<int32_t>(2 * (size_t)cs);
         push.theta = ar.take<double>(2 * (size_t)cs);
         push.active = ar.take<int32_t>(64);
-        team_ctl = ar.take<int32_t>(512);
+        (void)ar.take<int32_t>(512);                          // (layout kept in step with geo_sssp_workspace_bytes)
         {
             const size_t S = (size_t)std::min(nb * 16, CELL_ORDER_MAX_SOURCES);
             cell_adj = ar.take<uint32_t>(S * ((S + 31) / 32));
@@ -1302,7 +1229,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
         wsum = ar.take<double>(8);
         GEO_REQUIRE(bits && counts && stmp && lm_d && lm_key && lm_flags && wunits && wrange && push.near_lists &&
                         push.far_lists && push.near_bits && push.far_bits && push.near_cnt && push.far_cnt && push.far_slot &&
-                        push.theta && push.active && team_ctl && cell_adj && wsum,
+                        push.theta && push.active && cell_adj && wsum,
                     "geo_sssp_multi: workspace carve failed");
         chunk_count_kernel<<<geo::grid_for(n, 256, 2048), 256, 0, stream>>>(indptr, n, ccnt);
         GEO_LAUNCH_CHECK();
@@ -1628,7 +1555,7 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
                                    argmin_out, ws, ws_bytes, sweeps_out, stream_, 64);
     }
     int32_t total_sweeps = 0;
-    bool pushed = false, persistent = false;
+    bool pushed = false;
     // Sources that lie close together are relaxed together: a row is evaluated whenever ANY of its batch's 16
     // sources moved a neighbour, so with 16 scattered sources every row is re-evaluated as each of 16 fronts
     // passes (and their corrections cascade), with 16 neighbouring sources the fronts pass as one.  On graphs
@@ -1671,50 +1598,6 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
             };
             if (int rc = push_reset()) return rc;
             const int64_t plimit = 64 * (int64_t)n + 64;
-            // ---- all sweeps in one launch, a team of workgroups per XCD (push_persistent_kernel) ----
-            if (opt.sssp_push_persistent != 0) {
-                static int n_cu = 0, fits = -1;
-                if (fits < 0) {
-                    int devid = 0, per_cu = 0;
-                    hipDeviceProp_t prop;
-                    GEO_HIP_CHECK(hipGetDevice(&devid));
-                    GEO_HIP_CHECK(hipGetDeviceProperties(&prop, devid));
-                    n_cu = prop.multiProcessorCount;
-                    GEO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, push_persistent_kernel<true>, 512, 0));
-                    fits = per_cu >= 1 && n_cu >= 8 ? 1 : 0;
-                }
-                if (fits) {
-                    const int team = std::min(32, n_cu / 8);         // one workgroup per CU, 8 XCDs
-                    TeamCtl ctl{team_ctl, team_ctl + 256, team_ctl + 264};
-                    GEO_HIP_CHECK(hipMemsetAsync(team_ctl, 0, 512 * sizeof(int32_t), stream));
-                    GEO_HIP_CHECK(hipEventRecord(g_ev0, stream));
-                    const int32_t max_sweeps = (int32_t)std::min<int64_t>(plimit, 1 << 24);
-                    if (weights) push_persistent_kernel<true><<<8 * team, 512, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, push, delta, ctl, team, max_sweeps, 1 << 20);
-                    else push_persistent_kernel<false><<<8 * team, 512, 0, stream>>>(indptr, indices, weights, n, nb, w.dist, push, delta, ctl, team, max_sweeps, 1 << 20);
-                    GEO_LAUNCH_CHECK();
-                    GEO_HIP_CHECK(hipEventRecord(g_ev1, stream));
-                    int32_t hctl[16];
-                    GEO_HIP_CHECK(hipMemcpyAsync(hctl, team_ctl + 256, sizeof(hctl), hipMemcpyDeviceToHost, stream));
-                    GEO_HIP_CHECK(hipStreamSynchronize(stream));
-                    int32_t most = 0;
-                    for (int x = 0; x < 8; ++x) most = std::max(most, hctl[8 + x]);
-                    if (opt.sssp_trace) fprintf(stderr, "[sssp-push] persistent teams of %d: abort=%d, sweeps per XCD %d %d %d %d %d %d %d %d\n", team, hctl[0],
-                                                hctl[8], hctl[9], hctl[10], hctl[11], hctl[12], hctl[13], hctl[14], hctl[15]);
-                    if (hctl[0] == 0 && most < max_sweeps) {
-                        float ms = 0.f;
-                        GEO_HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
-                        g_last_sweep_ms += ms;
-                        total_sweeps += most;
-                        pushed = true;
-                        persistent = true;
-                        break;
-                    }
-                    // a block off its XCD, or a team that did not assemble: start over with one launch per sweep
-                    init_multi_kernel<<<geo::grid_for((int64_t)nb * n * sb, 256 * 8), 256, 0, stream>>>(w.dist, w.src_pad, n, nb, sb);
-                    GEO_LAUNCH_CHECK();
-                    if (int rc = push_reset()) return rc;
-                }
-            }
             const int bpb = opt.sssp_push_blocks > 0 ? opt.sssp_push_blocks : 64;
             const unsigned pgrid = (unsigned)(((nb + 7) / 8) * 8) * (unsigned)bpb;        // batch <-> XCD: see push_sweep_kernel
             int32_t sweeps = 0, hact = 1;
@@ -1835,8 +1718,8 @@ static int sssp_multi_impl(const int32_t *indptr, const int32_t *indices, const 
     }
     const int32_t sweeps = total_sweeps;
     if (sweeps_out) *sweeps_out = sweeps;
-    g_last_sweep_launches = persistent ? 1 : sweeps;                          // the persistent solve is ONE launch
-    g_last_layout = sb + (chunked ? 1000 : 0) + (pushed ? 3000 : 0) + (persistent ? 1000 : 0);   // 4016 near-far push solve, 5016 in one launch
+    g_last_sweep_launches = sweeps;
+    g_last_layout = sb + (chunked ? 1000 : 0) + (pushed ? 3000 : 0);   // 4016 near-far push solve
 
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)nb);
     if (D_out) {

@@ -37,7 +37,7 @@ from .._device import DeviceCSR, device
 from ..geo.kmeans_optimized import fit_kmedoids_optimized
 from ..geo.knn_graph_optimized import (compact_device, connected_components_device, knn_graph_device, upper_edges_device)
 from ..geo.riemannian_metric import edge_lengths_riemannian
-from ..vae import VAE
+from ..vae import decoder_from_vae_checkpoint
 
 N_BANDS = 5                     # Euclidean-weight bands of the subset mode
 _RUN_DIRS = {"mnist": "experiments/vae_mnist", "fashion": "experiments/vae_fashion", "cifar10": "experiments/vae_cifar10"}
@@ -99,9 +99,7 @@ def read_decoder(path: Path, vae_config: Dict, dev: torch.device) -> torch.nn.Mo
     blob = torch.load(path, map_location=dev)
     if not isinstance(blob, dict):
         raise ValueError("Expected checkpoint dict with model_state_dict")
-    vae = VAE(**vae_config)
-    vae.load_state_dict(blob.get("model_state_dict", blob))
-    return vae.to(dev).eval().decoder
+    return decoder_from_vae_checkpoint(blob.get("model_state_dict", blob), **vae_config).to(dev).eval()
 
 
 # ------------------------------------------------------------------------------------------------ device steps

@@ -1,31 +1,13 @@
-"""The vanilla (vector-latent) VAE of the legacy builders (reference src/models/vae.py:22-85,88-122): Linear -> ConvT
-decoder, conv encoder with Linear heads, same parameter names (a reference checkpoint loads unchanged).  Inference only
-(encode / decode): the legacy Riemannian builder differentiates `decoder` -- a Linear-first module, so
-edge_lengths_riemannian takes its autograd path on the GPU (riemannian_metric.py:18-22)."""
-from typing import Sequence, Tuple
+"""The decoder of the vanilla (vector-latent) VAE of the legacy builders (reference src/models/vae.py:53-85): Linear -> ConvT
+stack with the reference's parameter names, so the `decoder.*` entries of a reference checkpoint load unchanged.  The legacy
+Riemannian builder differentiates this module -- Linear-first, so edge_lengths_riemannian takes its autograd path on the GPU
+(riemannian_metric.py:18-22).  Encoder, loss and sampling of the reference's VAE are not part of the hot path and not built."""
+from typing import Dict, Sequence
 
 import torch
 import torch.nn as nn
 
 from .spatial_decoder import make_norm
-
-
-class Encoder(nn.Module):
-    def __init__(self, input_channels: int = 1, channels: Sequence[int] = (32, 64, 128), latent_dim: int = 16,
-                 norm_type: str = "none"):
-        super().__init__()
-        layers, prev = [], input_channels
-        for ch in channels:
-            layers += [nn.Conv2d(prev, ch, 3, stride=2, padding=1), make_norm(norm_type, ch), nn.ReLU(inplace=True)]
-            prev = ch
-        self.conv_layers = nn.Sequential(*layers)
-        self.feature_dim = channels[-1] * 4 * 4
-        self.fc_mu = nn.Linear(self.feature_dim, latent_dim)
-        self.fc_logvar = nn.Linear(self.feature_dim, latent_dim)
-
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        h = self.conv_layers(x).flatten(1)
-        return self.fc_mu(h), self.fc_logvar(h)
 
 
 class Decoder(nn.Module):
@@ -48,22 +30,11 @@ class Decoder(nn.Module):
         return self.output_layer(self.deconv2(self.deconv1(h)))
 
 
-class VAE(nn.Module):
-    def __init__(self, in_channels=1, enc_channels=(32, 64, 128), dec_channels=(128, 64, 32), latent_dim=16,
-                 recon_loss="bce", output_image_size: int = 28, norm_type: str = "none", mse_use_sigmoid: bool = True,
-                 **_training_defaults):
-        super().__init__()
-        assert recon_loss in {"bce", "mse"}, f"recon_loss must be 'bce' or 'mse', got {recon_loss}"
-        self.encoder = Encoder(in_channels, tuple(enc_channels), latent_dim, norm_type)
-        self.decoder = Decoder(in_channels, tuple(dec_channels), latent_dim, output_image_size, norm_type)
-        self.recon_loss, self.mse_use_sigmoid = recon_loss, mse_use_sigmoid
-
-    @staticmethod
-    def reparameterize(mu: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
-        std = torch.exp(0.5 * logvar)
-        return mu + torch.randn_like(std) * std
-
-    def forward(self, x: torch.Tensor):
-        mu, logvar = self.encoder(x)
-        z = self.reparameterize(mu, logvar)
-        return self.decoder(z), mu, logvar, z
+def decoder_from_vae_checkpoint(state: Dict[str, torch.Tensor], in_channels: int = 1, dec_channels: Sequence[int] = (128, 64, 32),
+                                latent_dim: int = 16, output_image_size: int = 28, norm_type: str = "none", **_other) -> Decoder:
+    """The decoder of a vanilla-VAE checkpoint (reference `VAE.state_dict()`: `encoder.*` and `decoder.*` entries).  Only the
+    `decoder.*` entries are read -- the builders differentiate the decoder and never encode -- and they must match exactly."""
+    dec = Decoder(in_channels, tuple(dec_channels), latent_dim, output_image_size, norm_type)
+    own = {k[len("decoder."):]: v for k, v in state.items() if k.startswith("decoder.")}
+    dec.load_state_dict(own if own else state)           # (a bare decoder state dict is accepted too)
+    return dec
