@@ -546,7 +546,8 @@ __device__ __forceinline__ void split3_pair(float a0, float a1, unsigned &w1, un
     w3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
-// B3[chunk][blk][part][ks][h][col][8] bf16: lane (col, h) of the 32x32x16 B operand reads 16 contiguous bytes
+// B3[chunk][blk][ks][h][part][col][8] bf16: lane (col, h) of the 32x32x16 B operand reads 16 contiguous bytes; the three parts of
+// a (block, k-step, half) lie 2 KB apart -- one address register and the immediate offsets -2048 / 0 / +2048 reach all three
 __global__ __launch_bounds__(256) void pack_mid_bf16_kernel(const float *__restrict__ B2p, int c1, int n_chunks,
                                                            unsigned short *__restrict__ B3) {
     const size_t per_blk = (size_t)c1 * NC;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void pack_mid_bf16_kernel(const float *__restr
         split3(B2p[i], p[0], p[1], p[2]);
         const int ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
         for (int part = 0; part < 3; ++part)
-            B3[(((cb * 3 + part) * (c1 / 16) + ks) * 2 + h) * (size_t)NC * 8 + (size_t)col * 8 + j] = p[part];
+            B3[(((cb * (c1 / 16) + ks) * 2 + h) * 3 + part) * (size_t)NC * 8 + (size_t)col * 8 + j] = p[part];
     }
 }
 
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 b[part][ks] = *reinterpret_cast<const bf16x8 *>(
-                    bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wave * 32 + r) * 8);
+                    bsrc + (((size_t)ks * 2 + h) * 3 + part) * (size_t)NC * 8 + (size_t)(wave * 32 + r) * 8);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -669,6 +670,142 @@ __global__ __launch_bounds__(256) void mid_bf16_kernel(const float *__restrict__
 // (and, in a persistent kernel, the epilogue's stores) at every phase.  Nothing here communicates through global memory inside a launch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- static geometry of ConvT2 (k4 s2 p1, 2x2 -> 4x4) in 8 chunks of two output pixels -- what make_chunks builds for
+// n_chunks == 8, opix_per_chunk == 2 (the host checks its table against these before taking the mid_all path) -------------
+//   chunk : output pixels      input pixels (block order)
+//     0   : (0,1) (0,2)        0 1          4 : (1,1) (1,2)   0 1 2 3
+//     1   : (3,1) (3,2)        2 3          5 : (2,1) (2,2)   0 1 2 3
+//     2   : (1,0) (2,0)        0 2          6 : (0,0) (0,3)   0 1
+//     3   : (1,3) (2,3)        1 3          7 : (3,0) (3,3)   2 3
+// Wave group 0 owns chunks {0,3,4,7}, group 1 {1,2,5,6}: ten (input pixel, chunk) products each, 2 or 3 per input pixel.
+struct MidGeom {
+    static __host__ __device__ constexpr int chunk_of(int wg, int lc) {
+        constexpr int t[2][4] = {{0, 3, 4, 7}, {1, 2, 5, 6}};
+        return t[wg][lc];
+    }
+    static __host__ __device__ constexpr int opix(int ch, int lo) {
+        constexpr int t[8][2] = {{1, 2}, {13, 14}, {4, 8}, {7, 11}, {5, 6}, {9, 10}, {0, 3}, {12, 15}};
+        return t[ch][lo];
+    }
+    // position of input pixel ip in the chunk's block list, -1 = the chunk does not read it
+    static __host__ __device__ constexpr int blk_of(int ch, int ip) {
+        constexpr int t[8][4] = {{0, 1, -1, -1}, {-1, -1, 0, 1}, {0, -1, 1, -1}, {-1, 0, -1, 1},
+                                 {0, 1, 2, 3},   {0, 1, 2, 3},   {0, 1, -1, -1}, {-1, -1, 0, 1}};
+        return t[ch][ip];
+    }
+    static __host__ __device__ constexpr int n_prod(int wg, int ip) {
+        int n = 0;
+        for (int lc = 0; lc < 4; ++lc) n += blk_of(chunk_of(wg, lc), ip) >= 0 ? 1 : 0;
+        return n;
+    }
+    static __host__ __device__ constexpr int prod_lc(int wg, int ip, int j) {   // j-th chunk slot of the group that reads pixel ip
+        int n = 0;
+        for (int lc = 0; lc < 4; ++lc)
+            if (blk_of(chunk_of(wg, lc), ip) >= 0) { if (n == j) return lc; ++n; }
+        return 0;
+    }
+    static __host__ __device__ constexpr int prod_cb(int wg, int ip, int j) {   // chunk * MAX_BLOCKS + block of that product
+        const int ch = chunk_of(wg, prod_lc(wg, ip, j));
+        return ch * MAX_BLOCKS + blk_of(ch, ip);
+    }
+    // ring slot of a pixel's first step: steps are numbered through the four pixels of a tile, slot = step % 3
+    static __host__ __device__ constexpr int ring_off(int wg, int ip, int ks_per_pixel) {
+        int n = 0;
+        for (int i = 0; i < ip; ++i) n += n_prod(wg, i) * ks_per_pixel;
+        return n % 3;
+    }
+};
+
+// The products of ONE input pixel for one wave: steps s = (k-step ks, product j), ks outer.  The A fragments of a k-step (three
+// split parts, primal and tangent: six 16-byte LDS reads) are read ONCE and feed every product of the pixel (2 or 3 chunks) --
+// the chunk-outer order of rounds 1-3 read them again per chunk -- and the NEXT k-step's are read while this one multiplies
+// (two register sets).  The B fragments (weights: L2 -> registers, 3 x 16 bytes per lane and step) run through a ring of three
+// register sets, issued two steps (24 MFMAs, ~770 cycles) before their use; the first two steps of the NEXT pixel are issued
+// before this pixel's last MFMAs so that the staging phase / barrier between pixels covers their latency.
+// Accumulation order per accumulator is unchanged (pixel, k-step, the six split products): results are bit-identical.
+template <int C1, bool TONLY, int WG, int IP>
+__device__ __forceinline__ void mid_products(const unsigned short *__restrict__ a_base,     // &A3[buf][0][0][r][h * 8]
+                                             __amdgpu_buffer_rsrc_t b_rsrc,                 // descriptor of B3 (wave-uniform)
+                                             unsigned b_lane,                               // this lane's BYTE offset inside a triple
+                                             f32x16 (&accp)[4], f32x16 (&acct)[4], bf16x8 (&ring)[3][3]) {
+    constexpr int KS = C1 / 16, LDK = C1 + 8;
+    constexpr int NP = MidGeom::n_prod(WG, IP);
+    constexpr int NSTEP = KS * NP;
+    constexpr int OFF = MidGeom::ring_off(WG, IP, KS);            // ring slot of this pixel's step 0
+    constexpr ptrdiff_t PART = (ptrdiff_t)NC * 8;                 // elements between the parts of a fragment triple
+    constexpr size_t A_PT = (size_t)TS * LDK, A_PART = 2 * A_PT;  // A3[buf][part][primal|tangent][row][k]
+    auto b_load = [&](int wg, int ip, int s, bf16x8 (&dst)[3]) {
+        const int ks = s / MidGeom::n_prod(wg, ip), j = s % MidGeom::n_prod(wg, ip);
+        // buffer loads: the descriptor and the block's byte offset are scalar, ONE per-lane 32-bit offset register serves every
+        // load of the kernel -- no vector address arithmetic, no 64-bit address pairs
+        const int soff = (int)((((ptrdiff_t)MidGeom::prod_cb(wg, ip, j) * KS + ks) * 2) * 3 * PART * 2);
+        dst[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, soff, 0));
+        dst[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, soff + (int)(PART * 2), 0));
+        dst[2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, soff + (int)(PART * 4), 0));
+    };
+    // ONE register set for the A fragments.  Within a step the six split products of an accumulator run in the order
+    // a3 b1, a2 b2, a2 b1, a1 b3, a1 b2, a1 b1 (small terms first), so a3 is free after the first pair of MFMAs of a k-step's
+    // LAST product, a2 after the third, a1 after the sixth: each part of the NEXT k-step is read into the registers its
+    // predecessor just left, at least six MFMAs (190 cycles) before its first use.
+    bf16x8 ap[3], at[3];
+    auto a_part = [&](int ks, int part) {
+        if (!TONLY) ap[part] = *reinterpret_cast<const bf16x8 *>(a_base + part * A_PART + ks * 16);
+        at[part] = *reinterpret_cast<const bf16x8 *>(a_base + part * A_PART + A_PT + ks * 16);
+    };
+    a_part(0, 2); a_part(0, 1); a_part(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TONLY ? 3 : 6, 0);    // (the pipeline below starts behind these reads)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int ks = s / NP, j = s % NP, slot = (OFF + s) % 3;
+        const int lc = MidGeom::prod_lc(WG, IP, j);
+        const bool reload = j == NP - 1 && ks + 1 < KS;          // last product of the k-step: refill A behind its last uses
+        if (s + 2 < NSTEP) b_load(WG, IP, s + 2, ring[(OFF + s + 2) % 3]);
+        else if (IP < 3) b_load(WG, IP + 1, s + 2 - NSTEP, ring[(OFF + s + 2) % 3]);     // the next pixel's first two steps
+        const bf16x8 (&b)[3] = ring[slot];
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0], acct[lc], 0, 0, 0);
+        if (reload) a_part(ks + 1, 2);
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1], acct[lc], 0, 0, 0);
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0], acct[lc], 0, 0, 0);
+        if (reload) a_part(ks + 1, 1);
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2], acct[lc], 0, 0, 0);
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1], acct[lc], 0, 0, 0);
+        if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0], accp[lc], 0, 0, 0);
+        acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0], acct[lc], 0, 0, 0);
+        if (reload) a_part(ks + 1, 0);
+        // pin the pipeline: left alone, the scheduler sinks every load to a few MFMAs before its use (register pressure
+        // heuristics) and the prefetch distance is gone.  Per step: the weight loads (for step s + 2) first, then the MFMAs with
+        // the LDS reads of the next k-step behind the pairs that free their registers.
+        constexpr int PAIR_M = TONLY ? 1 : 2, DS = TONLY ? 1 : 2;
+        if (s + 2 < NSTEP || IP < 3) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        if (reload) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PAIR_M, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * PAIR_M, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * PAIR_M, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * PAIR_M, 0);
+        }
+    }
+}
+
+#ifdef GEO_MID_PROF
+// per wave group (waves 0 and 4 report): [0] prologue + first staging, [1..4] the four pixel intervals up to their barrier,
+// [5] time parked in those barriers, [6] epilogue, [7] tiles
+__device__ unsigned long long g_mid_prof[2][8];
+#define GEO_MP_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define GEO_MP_ADD(slot, val) do { if (lane == 0 && wq == 0) atomicAdd(&g_mid_prof[wg][slot], (unsigned long long)(val)); } while (0)
+#else
+#define GEO_MP_STAMP(v)
+#define GEO_MP_ADD(slot, val)
+#endif
+
 // ---- all eight 128-column chunks of a tile in ONE workgroup (dec_channels[2] = 64) ----------------
 // Staging an input pixel's A block (norm1 + ReLU + 3-way split of 32 x C1 primal and tangent values) costs
 // about as much VALU time as the 96 bf16 MFMAs one chunk spends on it.  Here the block is staged once (by
@@ -682,7 +819,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int C1, bool GN, bool TONLY = false>
 __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
                                                         const NormConst *__restrict__ consts1, int consts_per_group,
-                                                        int tiles_per_group, ChunkTable tab, int c2,
+                                                        int tiles_per_group, int c2,
                                                         const unsigned short *__restrict__ B3,
                                                         const float *__restrict__ b2, float *__restrict__ pre2,
                                                         float *__restrict__ tpre2, double *__restrict__ partial2,
@@ -699,6 +836,7 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     constexpr int CPT = C1 / 16;                               // channels staged per thread
     __shared__ __attribute__((aligned(16))) unsigned short A3[2][3][2][TS][LDK];   // double buffered over input pixels
     __shared__ NormConst kc[C1];
+    GEO_MP_STAMP(mp0);
     const int tile = blockIdx.x;
     const int group = tile / tiles_per_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -768,6 +906,9 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                     rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
                     rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
                 }
+                // (a scheduling group of their own: otherwise these eight loads fill the first load groups of mid_products'
+                // pipeline and push every weight load two steps late)
+                __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
             }
         } else {
             unsigned short pp[3][CPT], pt[3][CPT];
@@ -791,66 +932,59 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                 const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)nx * C1 + k0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
-            }
-        }
-    };
-    auto products = [&](int ip, int buf) {
-#pragma unroll
-        for (int lc = 0; lc < NL; ++lc) {
-            const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
-            int blk = -1;                                      // position of this input pixel in the chunk's block list
-#pragma unroll
-            for (int j = 0; j < MAX_BLOCKS; ++j)
-                if (j < tab.nblk[ch] && tab.ipix[ch][j] == ip) blk = j;
-            if (blk < 0) continue;                             // wave-uniform
-            bf16x8 b[3][KS];
-            const unsigned short *bsrc = B3 + ((size_t)(ch * MAX_BLOCKS + blk) * 3 * KS * 2) * (size_t)NC * 8;
-#pragma unroll
-            for (int part = 0; part < 3; ++part)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    b[part][ks] = *reinterpret_cast<const bf16x8 *>(
-                        bsrc + (((size_t)part * KS + ks) * 2 + h) * (size_t)NC * 8 + (size_t)(wq * 32 + r) * 8);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 ap[3], at[3];
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    if (!TONLY) ap[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][0][r][ks * 16 + h * 8]);
-                    at[part] = *reinterpret_cast<const bf16x8 *>(&A3[buf][part][1][r][ks * 16 + h * 8]);
-                }
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0][ks], acct[lc], 0, 0, 0);
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[2][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[2][ks], acct[lc], 0, 0, 0);
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[1][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[1][ks], acct[lc], 0, 0, 0);
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], b[0][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], b[0][ks], acct[lc], 0, 0, 0);
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[1][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[1][ks], acct[lc], 0, 0, 0);
-                if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], b[0][ks], accp[lc], 0, 0, 0);
-                acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], b[0][ks], acct[lc], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * ((CPT + 3) / 4), 0);
             }
         }
     };
     // The two waves of a SIMD (w and w + 4 = the two chunk groups) take the phases of an input pixel in opposite order: waves 0-3
     // multiply pixel ip and then stage pixel ip + 1 into the other buffer, waves 4-7 stage first and multiply afterwards -- one
     // partner's vector / LDS-store work runs beside the other's MFMAs instead of both reaching the matrix pipe together.
+    bf16x8 ring[3][3];
+    const unsigned b_lane = (unsigned)(h * 3 * NC * 8 + (wq * 32 + r) * 8) * 2u;      // bytes
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(B3), 0, (int)((size_t)8 * MAX_BLOCKS * C1 * NC * 3 * 2), 0x00020000);
+    {   // the first two steps' weight fragments of pixel 0 (both wave groups): in flight during the first staging
+        const int cb0 = wg == 0 ? MidGeom::prod_cb(0, 0, 0) : MidGeom::prod_cb(1, 0, 0);
+        const int cb1 = wg == 0 ? MidGeom::prod_cb(0, 0, 1) : MidGeom::prod_cb(1, 0, 1);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            ring[0][part] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (cb0 * KS * 2 * 3 + part) * NC * 8 * 2, 0));
+            ring[1][part] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (cb1 * KS * 2 * 3 + part) * NC * 8 * 2, 0));
+        }
+    }
     stage_px(0, 1);
     if (wg == 1) __builtin_amdgcn_s_setprio(1);                // the later-dispatched half loses every issue arbitration otherwise
     lds_barrier();                                             // (LDS only: the next pixel's loads stay in flight)
-    for (int ip = 0; ip < 4; ++ip) {
-        const int buf = ip & 1;
-        if (wg == 0) {
-            products(ip, buf);
-            if (ip < 3) stage_px(buf ^ 1, ip + 2);
-        } else {
-            if (ip < 3) stage_px(buf ^ 1, ip + 2);
-            products(ip, buf);
-        }
-        if (ip < 3) lds_barrier();
+    GEO_MP_STAMP(mp1);
+    GEO_MP_ADD(0, mp1 - mp0);
+    const unsigned short *a_lane = &A3[0][0][0][r][h * 8];
+    constexpr size_t A_BUF = (size_t)3 * 2 * TS * LDK;
+    // (ring slots run through the four pixels of a tile: MidGeom::ring_off gives every pixel body its first slot)
+#define GEO_MID_PIXEL(WGV, IPV)                                                                                        \
+    mid_products<C1, TONLY, WGV, IPV>(a_lane + ((IPV) & 1) * A_BUF, b_rsrc, b_lane, accp, acct, ring)
+#ifdef GEO_MID_PROF
+    unsigned long long mp_prev = mp1, mp_wait = 0;
+#define GEO_MP_INTERVAL(slot, with_barrier)                                                                            \
+    { const unsigned long long t_a = __builtin_amdgcn_s_memtime();                                                      \
+      if (with_barrier) { lds_barrier(); }                                                                              \
+      const unsigned long long t_b = __builtin_amdgcn_s_memtime();                                                      \
+      GEO_MP_ADD(slot, t_a - mp_prev); mp_wait += t_b - t_a; mp_prev = t_b; }
+#else
+#define GEO_MP_INTERVAL(slot, with_barrier) { if (with_barrier) { lds_barrier(); } }
+#endif
+    if (wg == 0) {
+        GEO_MID_PIXEL(0, 0); stage_px(1, 2); GEO_MP_INTERVAL(1, true)
+        GEO_MID_PIXEL(0, 1); stage_px(0, 3); GEO_MP_INTERVAL(2, true)
+        GEO_MID_PIXEL(0, 2); stage_px(1, 4); GEO_MP_INTERVAL(3, true)
+        GEO_MID_PIXEL(0, 3); GEO_MP_INTERVAL(4, false)
+    } else {
+        stage_px(1, 2); GEO_MID_PIXEL(1, 0); GEO_MP_INTERVAL(1, true)
+        stage_px(0, 3); GEO_MID_PIXEL(1, 1); GEO_MP_INTERVAL(2, true)
+        stage_px(1, 4); GEO_MID_PIXEL(1, 2); GEO_MP_INTERVAL(3, true)
+        GEO_MID_PIXEL(1, 3); GEO_MP_INTERVAL(4, false)
     }
+#undef GEO_MP_INTERVAL
+#undef GEO_MID_PIXEL
 
     // rows of the tile that hold edges of the chunk (slot_valid_kernel's rule, computed here: no loads in the epilogue)
     int64_t cnt_g = n_edges - (e_base + (int64_t)(group >> 1) * batch);
@@ -863,8 +997,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     double sx = 0, sxx = 0, st_ = 0, sxt = 0;
 #pragma unroll
     for (int lc = 0; lc < NL; ++lc) {
-        const int ch = wg == 0 ? (lc == 0 ? 0 : lc == 1 ? 3 : lc == 2 ? 4 : 7) : (lc == 0 ? 1 : lc == 1 ? 2 : lc == 2 ? 5 : 6);
-        const int op = tab.opix[ch][lo];
+        const int ch = wg == 0 ? MidGeom::chunk_of(0, lc) : MidGeom::chunk_of(1, lc);
+        const int op = lo == 0 ? MidGeom::opix(ch, 0) : MidGeom::opix(ch, 1);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
@@ -888,6 +1022,10 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
             p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
         }
     }
+#ifdef GEO_MID_PROF
+    { const unsigned long long t_e = __builtin_amdgcn_s_memtime();
+      GEO_MP_ADD(6, t_e - mp_prev); GEO_MP_ADD(5, mp_wait); GEO_MP_ADD(7, 1); }
+#endif
 }
 
 __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
@@ -1309,6 +1447,17 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 
     ChunkTable tab;
     make_chunks(s, &tab);
+    if (s.n_chunks == 8 && s.opix_per_chunk == 2) {          // mid_all_kernel's compiled-in geometry must be this table
+        for (int ch = 0; ch < 8; ++ch) {
+            int nb = 0;
+            for (int ip = 0; ip < 4; ++ip) {
+                const int blk = MidGeom::blk_of(ch, ip);
+                if (blk >= 0) { GEO_REQUIRE(tab.ipix[ch][blk] == ip, "geo_decoder_jvp: chunk table / MidGeom mismatch (chunk %d)", ch); ++nb; }
+            }
+            GEO_REQUIRE(nb == tab.nblk[ch] && tab.opix[ch][0] == MidGeom::opix(ch, 0) && tab.opix[ch][1] == MidGeom::opix(ch, 1),
+                        "geo_decoder_jvp: chunk table / MidGeom mismatch (chunk %d)", ch);
+        }
+    }
     compose_front_kernel<<<geo::grid_for((int64_t)(s.d + 1) * s.n1, 256), 256, 0, stream>>>(
         dc->w_in, dc->b_in, dc->w1, dc->b1, s.d, s.c0, s.c1, M01, b01);
     GEO_LAUNCH_CHECK();
@@ -1382,7 +1531,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
             GEO_LAUNCH_CHECK();
         }
 #define GEO_MIDA_N(C1V, GNV)                                                                                       \
-    mid_all_kernel<C1V, GNV><<<(unsigned)nt_node, 512, 0, stream>>>(pre1, tpre1, k1, 0, (int)nt_node, tab, s.c2, B3,    \
+    mid_all_kernel<C1V, GNV><<<(unsigned)nt_node, 512, 0, stream>>>(pre1, tpre1, k1, 0, (int)nt_node, s.c2, B3,         \
                                                                     dc->b2, pre2_node, tpre2, part2, 0, slot_valid,   \
                                                                     gs1, 0, n_nodes, big_batch)
         if (gs1) { if (s.c1 == 128) GEO_MIDA_N(128, true); else if (s.c1 == 64) GEO_MIDA_N(64, true); else GEO_MIDA_N(32, true); }
@@ -1457,7 +1606,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                              mid_opt != 2;
         if (mid_all && per_node) {
 #define GEO_MIDA_T(C1V, GNV)                                                                                       \
-    mid_all_kernel<C1V, GNV, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group, tab,  \
+    mid_all_kernel<C1V, GNV, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group,       \
                                                                           s.c2, B3, dc->b2, pre2, tpre2, part2, 0,     \
                                                                           slot_valid, gs1, e_base, n_edges, batch)
             if (gs1) { if (s.c1 == 128) GEO_MIDA_T(128, true); else if (s.c1 == 64) GEO_MIDA_T(64, true); else GEO_MIDA_T(32, true); }
@@ -1468,7 +1617,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
         } else if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
-                                                                    pl.tiles_per_group, tab, s.c2, B3, dc->b2,      \
+                                                                    pl.tiles_per_group, s.c2, B3, dc->b2,           \
                                                                     pre2, tpre2, part2, batch_stats ? 1 : 0,        \
                                                                     slot_valid, gs1, e_base, n_edges, batch)
             if (gs1) {
@@ -1537,6 +1686,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 }
 
 }  // namespace
+
+#ifdef GEO_MID_PROF
+extern "C" int geo_debug_mid_prof(unsigned long long *out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_prof), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_prof), sizeof(unsigned long long) * 16);
+}
+#endif
 
 extern "C" size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size) {
     Plan pl;
