@@ -40,7 +40,7 @@ if f is not None:                       # a library built with -DGEO_MID_PROF: s
     f(buf, 1)
     edge_lengths_graph_device(ex, z, src, dst, 512); torch.cuda.synchronize()
     f(buf, 0)
-    names = ["prologue+S0", "interval0", "interval1", "interval2", "P3", "in barriers", "epilogue", "tiles"]
+    names = ["prologue+S0", "interval0", "interval1", "interval2", "interval3 (P3)", "in barriers", "epilogue", "tiles"]
     for g in (0, 1):
         n = max(1, buf[g * 8 + 7])
         print("wave group", g, {names[k]: round(buf[g * 8 + k] / n) for k in range(7)}, "cycles per tile; tiles", buf[g * 8 + 7], flush=True)

@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -708,10 +709,14 @@ struct MidGeom {
         const int ch = chunk_of(wg, prod_lc(wg, ip, j));
         return ch * MAX_BLOCKS + blk_of(ch, ip);
     }
-    // ring slot of a pixel's first step: steps are numbered through the four pixels of a tile, slot = step % 3
-    static __host__ __device__ constexpr int ring_off(int wg, int ip, int ks_per_pixel) {
+    // The input pixels are processed in the order 3, 2, 1, 0: group 0 then ends a tile with a two-product pixel and group 1 starts it
+    // with one -- the light pixel shares its interval with the group's epilogue in mid_pipe_kernel (19 900 instead of 23 000
+    // cycles for those two intervals).  Both ConvT2 kernels use this order, so their pre-activations stay bit-identical.
+    static __host__ __device__ constexpr int pix(int pos) { return 3 - pos; }
+    // ring slot of the first step of the pixel at position pos: steps are numbered through the four pixels of a tile, slot = step % 3
+    static __host__ __device__ constexpr int ring_off(int wg, int pos, int ks_per_pixel) {
         int n = 0;
-        for (int i = 0; i < ip; ++i) n += n_prod(wg, i) * ks_per_pixel;
+        for (int i = 0; i < pos; ++i) n += n_prod(wg, pix(i)) * ks_per_pixel;
         return n % 3;
     }
 };
@@ -723,15 +728,16 @@ struct MidGeom {
 // register sets, issued two steps (24 MFMAs, ~770 cycles) before their use; the first two steps of the NEXT pixel are issued
 // before this pixel's last MFMAs so that the staging phase / barrier between pixels covers their latency.
 // Accumulation order per accumulator is unchanged (pixel, k-step, the six split products): results are bit-identical.
-template <int C1, bool TONLY, int WG, int IP>
-__device__ __forceinline__ void mid_products(const unsigned short *__restrict__ a_base,     // &A3[buf][0][0][r][h * 8]
+template <int C1, bool TONLY, int WG, int POS>
+__device__ __forceinline__ void mid_products(const unsigned short *__restrict__ a3, unsigned a_idx,   // &A3[0]..., element index of [buf][0][0][r][h * 8]
                                              __amdgpu_buffer_rsrc_t b_rsrc,                 // descriptor of B3 (wave-uniform)
                                              unsigned b_lane,                               // this lane's BYTE offset inside a triple
                                              f32x16 (&accp)[4], f32x16 (&acct)[4], bf16x8 (&ring)[3][3]) {
     constexpr int KS = C1 / 16, LDK = C1 + 8;
+    constexpr int IP = MidGeom::pix(POS);                         // the input pixel at this position of the tile's sequence
     constexpr int NP = MidGeom::n_prod(WG, IP);
     constexpr int NSTEP = KS * NP;
-    constexpr int OFF = MidGeom::ring_off(WG, IP, KS);            // ring slot of this pixel's step 0
+    constexpr int OFF = MidGeom::ring_off(WG, POS, KS);           // ring slot of this pixel's step 0
     constexpr ptrdiff_t PART = (ptrdiff_t)NC * 8;                 // elements between the parts of a fragment triple
     constexpr size_t A_PT = (size_t)TS * LDK, A_PART = 2 * A_PT;  // A3[buf][part][primal|tangent][row][k]
     auto b_load = [&](int wg, int ip, int s, bf16x8 (&dst)[3]) {
@@ -748,6 +754,10 @@ __device__ __forceinline__ void mid_products(const unsigned short *__restrict__ 
     // LAST product, a2 after the third, a1 after the sixth: each part of the NEXT k-step is read into the registers its
     // predecessor just left, at least six MFMAs (190 cycles) before its first use.
     bf16x8 ap[3], at[3];
+    // (the index passes through an empty asm: the compiler can then neither fold it with the buffer's constant into offsets beyond
+    // the 16-bit immediate of ds_read, nor hoist one address register per read out of a persistent kernel's tile loop)
+    asm volatile("" : "+v"(a_idx));
+    const unsigned short *a_base = a3 + a_idx;
     auto a_part = [&](int ks, int part) {
         if (!TONLY) ap[part] = *reinterpret_cast<const bf16x8 *>(a_base + part * A_PART + ks * 16);
         at[part] = *reinterpret_cast<const bf16x8 *>(a_base + part * A_PART + A_PT + ks * 16);
@@ -760,7 +770,7 @@ __device__ __forceinline__ void mid_products(const unsigned short *__restrict__ 
         const int lc = MidGeom::prod_lc(WG, IP, j);
         const bool reload = j == NP - 1 && ks + 1 < KS;          // last product of the k-step: refill A behind its last uses
         if (s + 2 < NSTEP) b_load(WG, IP, s + 2, ring[(OFF + s + 2) % 3]);
-        else if (IP < 3) b_load(WG, IP + 1, s + 2 - NSTEP, ring[(OFF + s + 2) % 3]);     // the next pixel's first two steps
+        else if (POS < 3) b_load(WG, MidGeom::pix(POS + 1), s + 2 - NSTEP, ring[(OFF + s + 2) % 3]);   // the next pixel's first two steps
         const bf16x8 (&b)[3] = ring[slot];
         if (!TONLY) accp[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], b[0], accp[lc], 0, 0, 0);
         acct[lc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], b[0], acct[lc], 0, 0, 0);
@@ -781,7 +791,7 @@ __device__ __forceinline__ void mid_products(const unsigned short *__restrict__ 
         // heuristics) and the prefetch distance is gone.  Per step: the weight loads (for step s + 2) first, then the MFMAs with
         // the LDS reads of the next k-step behind the pairs that free their registers.
         constexpr int PAIR_M = TONLY ? 1 : 2, DS = TONLY ? 1 : 2;
-        if (s + 2 < NSTEP || IP < 3) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        if (s + 2 < NSTEP || POS < 3) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
         if (reload) {
             __builtin_amdgcn_sched_group_barrier(0x008, PAIR_M, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
@@ -792,6 +802,9 @@ __device__ __forceinline__ void mid_products(const unsigned short *__restrict__ 
         } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 6 * PAIR_M, 0);
         }
+        // every step is a scheduling region of its own: the order ACROSS steps is program order (what the ring needs), and the
+        // group solver sees 20 instructions instead of a pixel's 2 000 (compile time: minutes -> seconds)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -865,11 +878,11 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
         kB = kp[1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + k0p);
-            rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + k0p);
+            rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)MidGeom::pix(0) * C1 + k0p);
+            rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)MidGeom::pix(0) * C1 + k0p);
         }
     } else {
-        const float *xp = pre1 + (slot0 + ss) * n1 + k0, *xt = tpre1 + (slot0 + ss) * n1 + k0;
+        const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)MidGeom::pix(0) * C1 + k0, *xt = tpre1 + (slot0 + ss) * n1 + (size_t)MidGeom::pix(0) * C1 + k0;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
     }
@@ -883,7 +896,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
         gg1 = gs1[(slot0 + ss) * 32 + (threadIdx.x & 15) * 2 + 1];
     }
     __syncthreads();                                           // kc visible
-    // stage_px(buf, nx): normalise + ReLU + split the raw values held in registers into A3[buf], then fetch pixel nx's (nx < 4)
+    // stage_px(buf, nx): normalise + ReLU + split the raw values held in registers into A3[buf], then fetch those of the pixel at
+    // position nx of the sequence (nx < 4)
     auto stage_px = [&](int buf, int nx) {
         if (PAIR) {
 #pragma unroll
@@ -903,8 +917,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
             if (nx < 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
-                    rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)nx * C1 + k0p);
+                    rp[i] = *reinterpret_cast<const f32x2 *>(pre1 + (slot0 + s0p + i) * n1 + (size_t)MidGeom::pix(nx) * C1 + k0p);
+                    rt[i] = *reinterpret_cast<const f32x2 *>(tpre1 + (slot0 + s0p + i) * n1 + (size_t)MidGeom::pix(nx) * C1 + k0p);
                 }
                 // (a scheduling group of their own: otherwise these eight loads fill the first load groups of mid_products'
                 // pipeline and push every weight load two steps late)
@@ -928,8 +942,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
                     A3[buf][part][1][ss][k0 + k] = pt[part][k];
                 }
             if (nx < 4) {
-                const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)nx * C1 + k0;
-                const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)nx * C1 + k0;
+                const float *xp = pre1 + (slot0 + ss) * n1 + (size_t)MidGeom::pix(nx) * C1 + k0;
+                const float *xt = tpre1 + (slot0 + ss) * n1 + (size_t)MidGeom::pix(nx) * C1 + k0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) { rawp[k] = xp[k]; rawt[k] = xt[k]; }
                 __builtin_amdgcn_sched_group_barrier(0x020, 2 * ((CPT + 3) / 4), 0);
@@ -944,8 +958,8 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short *>(B3), 0, (int)((size_t)8 * MAX_BLOCKS * C1 * NC * 3 * 2), 0x00020000);
     {   // the first two steps' weight fragments of pixel 0 (both wave groups): in flight during the first staging
-        const int cb0 = wg == 0 ? MidGeom::prod_cb(0, 0, 0) : MidGeom::prod_cb(1, 0, 0);
-        const int cb1 = wg == 0 ? MidGeom::prod_cb(0, 0, 1) : MidGeom::prod_cb(1, 0, 1);
+        const int cb0 = wg == 0 ? MidGeom::prod_cb(0, MidGeom::pix(0), 0) : MidGeom::prod_cb(1, MidGeom::pix(0), 0);
+        const int cb1 = wg == 0 ? MidGeom::prod_cb(0, MidGeom::pix(0), 1) : MidGeom::prod_cb(1, MidGeom::pix(0), 1);
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             ring[0][part] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (cb0 * KS * 2 * 3 + part) * NC * 8 * 2, 0));
@@ -957,11 +971,12 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     lds_barrier();                                             // (LDS only: the next pixel's loads stay in flight)
     GEO_MP_STAMP(mp1);
     GEO_MP_ADD(0, mp1 - mp0);
-    const unsigned short *a_lane = &A3[0][0][0][r][h * 8];
-    constexpr size_t A_BUF = (size_t)3 * 2 * TS * LDK;
+    const unsigned short *a3 = &A3[0][0][0][0][0];
+    const unsigned a_lane = (unsigned)(r * LDK + h * 8);
+    constexpr unsigned A_BUF = 3u * 2u * TS * LDK;
     // (ring slots run through the four pixels of a tile: MidGeom::ring_off gives every pixel body its first slot)
 #define GEO_MID_PIXEL(WGV, IPV)                                                                                        \
-    mid_products<C1, TONLY, WGV, IPV>(a_lane + ((IPV) & 1) * A_BUF, b_rsrc, b_lane, accp, acct, ring)
+    mid_products<C1, TONLY, WGV, IPV>(a3, a_lane + ((IPV) & 1) * A_BUF, b_rsrc, b_lane, accp, acct, ring)
 #ifdef GEO_MID_PROF
     unsigned long long mp_prev = mp1, mp_wait = 0;
 #define GEO_MP_INTERVAL(slot, with_barrier)                                                                            \
@@ -1026,6 +1041,232 @@ __global__ __launch_bounds__(512, 2) void mid_all_kernel(const float *__restrict
     { const unsigned long long t_e = __builtin_amdgcn_s_memtime();
       GEO_MP_ADD(6, t_e - mp_prev); GEO_MP_ADD(5, mp_wait); GEO_MP_ADD(7, 1); }
 #endif
+}
+
+// ---- ConvT2, persistent and skewed (dec_channels 128 -> 64, BatchNorm or no norm): the default for the shipped decoder ------
+// In-kernel stamps of mid_all_kernel (one tile per workgroup, -DGEO_MID_PROF): the four pixel intervals keep the matrix pipe 85 %
+// busy, but the tile's prologue (constants, first staging: 9 100 cycles) and epilogue (128 stores per wave + fp64 statistics:
+// 13 800) run with NO MFMA beside them -- a quarter of the 95 600 cycles of a tile.  Here ONE workgroup per CU walks over its tiles
+// and the two wave groups (waves 0-3 / 4-7 = the two chunk groups, one wave of each per SIMD) trade those phases:
+//     interval 0 : group 0  P0, stage pixel 1 (all 32 samples)      group 1  EPILOGUE of the previous tile, P0
+//     interval 1 : group 0  P1, stage half of pixel 2                 group 1  stage half of pixel 2, P1
+//     interval 2 : group 0  P2, stage half of pixel 3                 group 1  stage half of pixel 3, P2
+//     interval 3 : group 0  P3, EPILOGUE of this tile                 group 1  stage pixel 0 of the NEXT tile (all samples), P3
+// (one LDS-only barrier after each interval; Pk = the products of the k-th input pixel of the sequence 3, 2, 1, 0, mid_products).  One group's stores / statistics /
+// staging always run beside the other group's MFMAs.  The statistics leave per wave (partial2 [tile][4 wave slots][channel],
+// finalize_batch_kernel adds them: npx_stored = 4), so no epilogue needs a workgroup barrier.  Same products in the same order as
+// mid_all_kernel: pre-activations are bit-identical; the fp64 statistic sums associate differently (last-bit differences).
+__global__ __launch_bounds__(512, 2) void mid_pipe_kernel(const float *__restrict__ pre1, const float *__restrict__ tpre1,
+                                                         const NormConst *__restrict__ consts1, int consts_per_group,
+                                                         int tiles_per_group, int n_tiles, int /*c2 == 64*/,
+                                                         const unsigned short *__restrict__ B3, const float *__restrict__ b2,
+                                                         float *__restrict__ pre2, float *__restrict__ tpre2,
+                                                         double *__restrict__ partial2, int want_stats, int64_t e_base,
+                                                         int64_t n_edges, int batch) {
+    constexpr int C1 = 128, LDK = C1 + 8, KS = C1 / 16, NL = 4, c2 = 64;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) unsigned short A3[2][3][2][TS][LDK];   // double buffered over input pixels
+    // (readfirstlane: everything derived from the wave number is then provably wave-uniform -- scalar branches on the chunk group,
+    // scalar offsets for the buffer loads / stores below instead of a 64-bit address pair per access)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wq = wave & 3, wg = wave >> 2;                   // column quarter, chunk group
+    constexpr int n1 = 4 * C1, n2 = 16 * c2;
+    const int r = lane & 31, h = lane >> 5;
+    const int k0p = 2 * lane;                                  // the lane's channel pair when staging
+    const int lo = wq >> 1, co = (wq & 1) * 32 + r;            // output pixel of the chunk (wave-uniform), channel
+    const float bias = b2[co];
+    const unsigned v_out = (unsigned)(4 * h * n2 + co) * 4u;    // the lane's byte offset inside a tile of pre2 / tpre2
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+
+    f32x16 accp[NL], acct[NL];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int lc = 0; lc < NL; ++lc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accp[lc][i] = 0.f; acct[lc][i] = 0.f; }
+    };
+    zero_acc();
+    // staging state of this wave: constants of the tile it stages next, and raw pre-activations in flight
+    NormConst kA, kB;
+    f32x2 rp[4], rt[4];
+    auto load_consts = [&](int tile) {
+        const NormConst *kp = consts1 + (size_t)(consts_per_group ? tile / tiles_per_group : 0) * C1 + k0p;
+        kA = kp[0];
+        kB = kp[1];
+    };
+    // raw values of NS samples (sample0 ...) of input pixel px of a tile -> rp / rt (in flight until stage())
+    // (per-tile buffer descriptors: the tile's base is scalar arithmetic, the lane contributes ONE loop-invariant 32-bit offset)
+    const unsigned v_pair = (unsigned)k0p * 4u;
+    auto fetch = [&](int tile, int px, int sample0, auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        const size_t tbase = (size_t)tile * TS * n1;
+        const __amdgpu_buffer_rsrc_t rp_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pre1 + tbase), 0, TS * n1 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tpre1 + tbase), 0, TS * n1 * 4, 0x00020000);
+        const int soff = (sample0 * n1 + MidGeom::pix(px) * C1) * 4;      // (px = position in the tile's pixel sequence)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            rp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rp_src, v_pair, soff + i * n1 * 4, 0));
+            rt[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rt_src, v_pair, soff + i * n1 * 4, 0));
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * NS, 0);  // (a group of their own: see mid_all_kernel's stage_px)
+    };
+    // norm1 + ReLU + 3-way split of the fetched values into A3[buf]
+    auto stage = [&](int buf, int sample0, auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        // one address register per call (empty asm: not folded, not hoisted out of the tile loop), everything else immediates
+        unsigned w_idx = (unsigned)((buf * 3 * 2 * TS + sample0) * LDK + k0p);
+        asm volatile("" : "+v"(w_idx));
+        unsigned short *w = &A3[0][0][0][0][0] + w_idx;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float a0, t0, a1, t1;
+            norm_relu(kA, rp[i].x, rt[i].x, &a0, &t0);
+            norm_relu(kB, rp[i].y, rt[i].y, &a1, &t1);
+            unsigned wa[3], wt[3];
+            split3_pair(a0, a1, wa[0], wa[1], wa[2]);
+            split3_pair(t0, t1, wt[0], wt[1], wt[2]);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                *reinterpret_cast<unsigned *>(w + (part * 2 + 0) * TS * LDK + i * LDK) = wa[part];
+                *reinterpret_cast<unsigned *>(w + (part * 2 + 1) * TS * LDK + i * LDK) = wt[part];
+            }
+        }
+    };
+    std::integral_constant<int, 4> HALF;
+    const int s_half = 4 * wave, s_full = 8 * wq;              // first sample a wave stages in the two modes
+
+    // weight fragments: buffer descriptor + ring (mid_products)
+    bf16x8 ring[3][3];
+    const unsigned b_lane = (unsigned)(h * 3 * NC * 8 + (wq * 32 + r) * 8) * 2u;      // bytes
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(B3), 0, (int)((size_t)8 * MAX_BLOCKS * C1 * NC * 3 * 2), 0x00020000);
+    auto ring_init = [&]() {                                   // the first two steps of pixel 0 (ring slots 0, 1)
+        const int cb0 = wg == 0 ? MidGeom::prod_cb(0, MidGeom::pix(0), 0) : MidGeom::prod_cb(1, MidGeom::pix(0), 0);
+        const int cb1 = wg == 0 ? MidGeom::prod_cb(0, MidGeom::pix(0), 1) : MidGeom::prod_cb(1, MidGeom::pix(0), 1);
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            ring[0][part] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (cb0 * KS * 2 * 3 + part) * NC * 8 * 2, 0));
+            ring[1][part] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (cb1 * KS * 2 * 3 + part) * NC * 8 * 2, 0));
+        }
+    };
+    // stores + statistics of one tile's accumulators (this wave's four chunks), then the accumulators start over
+    auto epilogue = [&](int tile) {
+        const int group = tile / tiles_per_group;
+        int64_t cnt_g = n_edges - (e_base + (int64_t)(group >> 1) * batch);
+        if (cnt_g > batch) cnt_g = batch;
+        const int n_valid = (int)cnt_g - (tile - group * tiles_per_group) * TS;
+        const size_t tbase = (size_t)tile * TS * n2;
+        const __amdgpu_buffer_rsrc_t p_dst = __builtin_amdgcn_make_buffer_rsrc(pre2 + tbase, 0, TS * n2 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t t_dst = __builtin_amdgcn_make_buffer_rsrc(tpre2 + tbase, 0, TS * n2 * 4, 0x00020000);
+        double sx = 0, sxx = 0, st_ = 0, sxt = 0;
+#pragma unroll
+        for (int lc = 0; lc < NL; ++lc) {
+            const int ch = wg == 0 ? MidGeom::chunk_of(0, lc) : MidGeom::chunk_of(1, lc);
+            const int op = lo == 0 ? MidGeom::opix(ch, 0) : MidGeom::opix(ch, 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float x = accp[lc][q] + bias, t = acct[lc][q];
+                const int soff = (((q & 3) + 8 * (q >> 2)) * n2 + op * c2) * 4;          // scalar; the lane adds v_out
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), p_dst, v_out, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), t_dst, v_out, soff, 0);
+                // (no branch per element: rows beyond the chunk's edges contribute zeros; all but a batch's last tile are full)
+                const double xd = row < n_valid ? (double)x : 0.0, td = row < n_valid ? (double)t : 0.0;
+                sx += xd; sxx = fma(xd, xd, sxx); st_ += td; sxt = fma(xd, td, sxt);
+            }
+        }
+        if (want_stats) {
+            sx += __shfl_xor(sx, 32, 64); sxx += __shfl_xor(sxx, 32, 64);
+            st_ += __shfl_xor(st_, 32, 64); sxt += __shfl_xor(sxt, 32, 64);
+            if (lane < 32) {                                   // wave slot = (chunk group, column half): channels (wq & 1) * 32 + lane
+                double *pp = partial2 + (((size_t)tile * 4 + (wg * 2 + (wq >> 1))) * c2 + co) * 4;
+                pp[0] = sx; pp[1] = sxx; pp[2] = st_; pp[3] = sxt;
+            }
+        }
+        zero_acc();
+    };
+
+    const unsigned short *a3 = &A3[0][0][0][0][0];
+    const unsigned a_lane = (unsigned)(r * LDK + h * 8);
+    constexpr unsigned A_BUF = 3u * 2u * TS * LDK;
+#define GEO_PIPE_PIXEL(WGV, IPV)                                                                                       \
+    mid_products<C1, false, WGV, IPV>(a3, a_lane + ((IPV) & 1) * A_BUF, b_rsrc, b_lane, accp, acct, ring)
+
+    // "all samples" by one group = two passes of four samples per wave through the same registers: the first four were fetched
+    // an interval ago, the second four are fetched behind the first staging and their latency is exposed -- in a group that has
+    // 10 000 cycles of slack in that interval (the other group is in its epilogue)
+#define GEO_PIPE_SEP() __builtin_amdgcn_sched_barrier(0)
+#define GEO_STAGE_FULL(BUF, TILE, PX)                                                                                   \
+    { stage(BUF, s_full, HALF); fetch(TILE, PX, s_full + 4, HALF); GEO_PIPE_SEP(); stage(BUF, s_full + 4, HALF); }
+
+    // ---- prologue: pixel 0 of the first tile, staged by halves; group 0 already fetches the first half of its pixel 1
+    int tile = blockIdx.x;
+    load_consts(tile);
+    fetch(tile, 0, s_half, HALF);
+    ring_init();
+    stage(0, s_half, HALF);
+    if (wg == 0) fetch(tile, 1, s_full, HALF);
+    else fetch(tile, 2, s_half, HALF);
+    // Matrix-pipe priority to the group whose vector work (staging, epilogue) FOLLOWS its products in an interval -- group 0 in all
+    // four: its MFMAs go first and its tail runs beside group 1's MFMAs.  (Measured the other way round, -DGEO_MID_PROF: group 1's
+    // products first, then group 0's, then group 0's staging alone: 18 400 cycles for an interval whose pipe work is 15 300.)
+    if (wg == 0) __builtin_amdgcn_s_setprio(1);
+    lds_barrier();
+    // (one tile loop per wave group: both run the same number of barriers per tile; separate loops keep the register allocator
+    // from reconciling the two groups' live ranges at every iteration)
+#ifdef GEO_MID_PROF
+    unsigned long long pb_prev = __builtin_amdgcn_s_memtime(), pb_wait = 0;
+#define GEO_PB(slot)                                                                                                   \
+    { const unsigned long long t_a = __builtin_amdgcn_s_memtime();                                                      \
+      lds_barrier();                                                                                                    \
+      const unsigned long long t_b = __builtin_amdgcn_s_memtime();                                                      \
+      if (lane == 0 && wq == 0) { atomicAdd(&g_mid_prof[wg][1 + slot], t_a - pb_prev); atomicAdd(&g_mid_prof[wg][5], t_b - t_a);   \
+                                  if (slot == 3) atomicAdd(&g_mid_prof[wg][7], 1ull); }                                 \
+      pb_prev = t_b; }
+#else
+#define GEO_PB(slot) lds_barrier();
+#endif
+    if (wg == 0) {
+        for (int it = 0; it < my_tiles; ++it) {
+            const int next = tile + (int)gridDim.x;
+            const bool has_next = it + 1 < my_tiles;
+            GEO_PIPE_PIXEL(0, 0); GEO_PIPE_SEP();
+            GEO_STAGE_FULL(1, tile, 1); fetch(tile, 2, s_half, HALF); GEO_PB(0);
+            GEO_PIPE_PIXEL(0, 1); GEO_PIPE_SEP(); stage(0, s_half, HALF); fetch(tile, 3, s_half, HALF); GEO_PB(1);
+            GEO_PIPE_PIXEL(0, 2); GEO_PIPE_SEP(); stage(1, s_half, HALF); GEO_PB(2);
+            GEO_PIPE_PIXEL(0, 3); GEO_PIPE_SEP();
+            epilogue(tile);
+            GEO_PIPE_SEP();
+            if (has_next) { load_consts(next); fetch(next, 1, s_full, HALF); ring_init(); }
+            GEO_PB(3);
+            tile = next;
+        }
+    } else {
+        // (raising group 1's priority for its vector phases -- staging, epilogue -- was measured: 18.0 ms against 17.7 ms, they slow
+        // group 0's product stream more than they gain)
+        for (int it = 0; it < my_tiles; ++it) {
+            const int next = tile + (int)gridDim.x;
+            const bool has_next = it + 1 < my_tiles;
+            if (it > 0) { epilogue(tile - (int)gridDim.x); GEO_PIPE_SEP(); ring_init(); }
+            GEO_PIPE_PIXEL(1, 0); GEO_PB(0);
+            stage(0, s_half, HALF); fetch(tile, 3, s_half, HALF); GEO_PIPE_SEP();
+            GEO_PIPE_PIXEL(1, 1); GEO_PB(1);
+            stage(1, s_half, HALF);
+            if (has_next) { load_consts(next); fetch(next, 0, s_full, HALF); }
+            GEO_PIPE_SEP();
+            GEO_PIPE_PIXEL(1, 2); GEO_PB(2);
+            if (has_next) { GEO_STAGE_FULL(0, next, 0); fetch(next, 2, s_half, HALF); }
+            GEO_PIPE_SEP();
+            GEO_PIPE_PIXEL(1, 3); GEO_PB(3);
+            tile = next;
+        }
+        epilogue(tile - (int)gridDim.x);                         // the last tile of group 1
+    }
+#undef GEO_STAGE_FULL
+#undef GEO_PIPE_SEP
+#undef GEO_PB
+#undef GEO_PIPE_PIXEL
 }
 
 __global__ __launch_bounds__(256) void slot_valid_kernel(int64_t e_base, int64_t n_edges, int batch, int tiles_per_group,
@@ -1604,6 +1845,8 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                                                     batch_stats ? 1 : 0, slot_valid)
         const bool mid_all = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 &&
                              mid_opt != 2;
+        // the shipped widths with BatchNorm / no norm, primal + tangent: the persistent skewed kernel (jvp_mid = 3: mid_all_kernel)
+        const bool mid_pipe = mid_all && !per_node && !gs1 && s.c1 == 128 && s.c2 == 64 && mid_opt != 3;
         if (mid_all && per_node) {
 #define GEO_MIDA_T(C1V, GNV)                                                                                       \
     mid_all_kernel<C1V, GNV, true><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, 0, pl.tiles_per_group,       \
@@ -1614,6 +1857,19 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
             else if (s.c1 == 64) GEO_MIDA_T(64, false);
             else GEO_MIDA_T(32, false);
 #undef GEO_MIDA_T
+        } else if (mid_pipe) {
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int devid = 0;
+                hipDeviceProp_t prop;
+                GEO_HIP_CHECK(hipGetDevice(&devid));
+                GEO_HIP_CHECK(hipGetDeviceProperties(&prop, devid));
+                n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            const unsigned pgrid = (unsigned)std::min<int64_t>(p_tiles, n_cu);      // one persistent workgroup per CU
+            mid_pipe_kernel<<<pgrid, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_tiles,
+                                                       s.c2, B3, dc->b2, pre2, tpre2, part2, batch_stats ? 1 : 0, e_base,
+                                                       n_edges, batch);
         } else if (mid_all) {
 #define GEO_MIDA(C1V, GNV)                                                                                         \
     mid_all_kernel<C1V, GNV><<<(unsigned)p_tiles, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0,           \
@@ -1642,7 +1898,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
         GEO_LAUNCH_CHECK();
         if (batch_stats) {
             finalize_batch_kernel<<<geo::grid_for(p_groups * s.c2, 256), 256, 0, stream>>>(
-                part2, pl.tiles_per_group, mid_all ? 1 : 16, 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups,
+                part2, pl.tiles_per_group, mid_pipe ? 4 : (mid_all ? 1 : 16), 16, s.c2, e_base, n_edges, batch, dc->g2, dc->be2, dc->eps, k2, (int)p_groups,
                 track ? stats : nullptr);
             if (track)
                 running_update_kernel<<<(unsigned)((s.c2 + 7) / 8), 256, 0, stream>>>(stats, (int)p_groups, s.c2, dc->momentum,
