@@ -9,7 +9,7 @@ TAG=${1:-r01_f}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 400 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
     python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 # the same command with ONE build after the other: the solo per-launch average of the sweep kernel in a rocprof CSV (roofline.frac)
