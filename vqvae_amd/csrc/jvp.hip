@@ -1814,7 +1814,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                                                                  pl.tiles_per_group, s.d, s.n1, M01, b01, pre1,       \
                                                                  tpre1, part1, batch_stats ? 1 : 0)
         const bool front_mfma = s.d > 16 && s.n1 % 32 == 0 && geo::options().jvp_front_valu == 0;
-        if (s.d <= 16) GEO_FRONT(16);
+        if (s.d <= 16) { if (geo::options().jvp_front_valu == 2 && s.n1 % 32 == 0) GEO_FRONT_MFMA(16); else GEO_FRONT(16); }
         else if (s.d <= 32) { if (front_mfma) GEO_FRONT_MFMA(32); else GEO_FRONT(32); }
         else { if (front_mfma) GEO_FRONT_MFMA(64); else GEO_FRONT(64); }
 #undef GEO_FRONT_MFMA
