@@ -271,20 +271,39 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
     const int l0 = bid * SUM_LEAVES;
     const int l1 = l0 + SUM_LEAVES < n_leaves ? l0 + SUM_LEAVES : n_leaves;
     const int32_t b0 = pl.leaf_start[l0], b1 = pl.leaf_start[l1 - 1] + pl.leaf_len[l1 - 1];
-    for (int32_t i = b0 + threadIdx.x; i < b1; i += 256) {
-        float x = dmin[i];
-        if (fuse_finish) {
-            const double dd = d[i];
-            if (dd < inf64()) {                            // reached by the solve of centre `pos`
-                const float xd = (float)dd;
-                if (xd < x) { x = xd; dmin[i] = xd; argmin[i] = pos; }
-                d[i] = inf64();
+    // (all of a thread's loads first: 16 dependent iterations of load -> store cost a memory latency each, 20-30 us per centre at
+    // one million latents with 245 blocks on the chip)
+    {
+        constexpr int PER = SUM_LEAVES * PW_BLOCK / 256;
+        float xs[PER];
+        double dds[PER];
+        uint8_t ics[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int32_t i = b0 + threadIdx.x + k * 256;
+            xs[k] = 0.0f; dds[k] = inf64(); ics[k] = 0;
+            if (i < b1) {
+                xs[k] = dmin[i];
+                if (fuse_finish) dds[k] = d[i];
+                ics[k] = is_center[i];
             }
         }
-        const float safe = any_finite ? (x < inf32() ? x : sub) : 1.0f;
-        const float p = is_center[i] ? 0.0f : safe * safe;
-        probs[i] = p;
-        sp[i - b0] = p;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int32_t i = b0 + threadIdx.x + k * 256;
+            if (i < b1) {
+                float x = xs[k];
+                if (fuse_finish && dds[k] < inf64()) {             // reached by the solve of centre `pos`
+                    const float xd = (float)dds[k];
+                    if (xd < x) { x = xd; dmin[i] = xd; argmin[i] = pos; }
+                    d[i] = inf64();
+                }
+                const float safe = any_finite ? (x < inf32() ? x : sub) : 1.0f;
+                const float p = ics[k] ? 0.0f : safe * safe;
+                probs[i] = p;
+                sp[i - b0] = p;
+            }
+        }
     }
     __syncthreads();
     {
@@ -341,8 +360,18 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
         }
-        if (threadIdx.x == 0)
+        // The chunk roots are accumulated IN ORDER by one thread (numpy adds its 8 192-element buffers one after the other) -- but
+        // fetched by all threads first: a single thread's `total += val[chunk_root[c]]` is two dependent device-scope round trips
+        // per chunk, 123 chunks at one million latents = the ~63 us this phase took per centre (kernel trace of the C4 chain,
+        // round 4: 1.5 such launches per centre, 60 % of the chain's time).
+        if (n_chunks <= SUM_LEAVES * PW_BLOCK) {
+            for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) sp[c] = ld_dev(&val[pl.chunk_root[c]]);
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int c = 0; c < n_chunks; ++c) total += sp[c];
+        } else if (threadIdx.x == 0) {
             for (int c = 0; c < n_chunks; ++c) total += ld_dev(&val[pl.chunk_root[c]]);
+        }
     }
     *total_out = total;
     return true;
@@ -375,50 +404,65 @@ __global__ __launch_bounds__(256) void kpp_sum_kernel(KppCtl *ctl, float *__rest
 // Last block: exclusive tile offsets, idx = searchsorted(cdf / cdf[-1], u, side='right') with a safety margin
 // around u -- first the tile whose first value is the last one <= u, then the position inside it.  Returns true in
 // that block, with the pick in pick[0..2] = {found, index, margin ok} (shared memory).
+// One tile's inclusive fp64 scan of p = float64(probs / total): thread t owns SCAN_I consecutive elements (sequential sums), wave
+// scan, wave bases.  v[i] + *excl is the tile-local inclusive value of the thread's i-th element; returns the tile total.  The same
+// code produces the tile totals (every block) and, in the last block, the values inside the picked tile: identical arithmetic.
+__device__ __forceinline__ double kpp_tile_scan(const float *__restrict__ probs, float total, int32_t n, int tile, double (&v)[SCAN_I],
+                                                double *excl, double *wtot) {
+    const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        const double p = (base + i < n) ? (double)(probs[base + i] / total) : 0.0;
+        run += p;
+        v[i] = run;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    double wbase = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < SCAN_T / 64; ++w) {
+        if (w < wave) wbase += wtot[w];
+        tot += wtot[w];
+    }
+    *excl = wbase + inc - run;
+    return tot;
+}
+
+// The draw.  Every block: its tile's total (the scan above).  Last block: exclusive tile offsets, idx = searchsorted(cdf / cdf[-1],
+// u, side='right') with a safety margin around u -- first the tile whose first value is the last one <= u, then the position inside
+// it, from a second scan of THAT tile (round 3 wrote all n cdf values with device-scope stores in every draw and read a few of them
+// back: 8 MB per centre at one million latents).  Returns true in that block, with the pick in pick[0..2] = {found, index, margin ok}.
 __device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const float *__restrict__ probs, int32_t n,
                                               double *cdf, double *tile_sum, int n_tiles, double u, double tol,
                                               int bid, int nblocks, int32_t *pick) {
     extern __shared__ __attribute__((aligned(16))) double toff[];          // [n_tiles + 1]
     __shared__ double wtot[SCAN_T / 64];
+    __shared__ double ctile[SCAN_TILE + 1];                                // cdf / cdf[-1] inside the picked tile (+ the next value)
     __shared__ int32_t s_tile;
+    (void)cdf;
     {
-        const int64_t base = (int64_t)bid * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
-        double v[SCAN_I];
-        double run = 0.0;
-#pragma unroll
-        for (int i = 0; i < SCAN_I; ++i) {
-            const double p = (base + i < n) ? (double)(probs[base + i] / total) : 0.0;
-            run += p;
-            v[i] = run;
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double inc = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        double wbase = 0.0, tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < SCAN_T / 64; ++w) {
-            if (w < wave) wbase += wtot[w];
-            tot += wtot[w];
-        }
-        const double excl = wbase + inc - run;
-#pragma unroll
-        for (int i = 0; i < SCAN_I; ++i)
-            if (base + i < n) st_dev(&cdf[base + i], excl + v[i]);
+        double v[SCAN_I], excl;
+        const double tot = kpp_tile_scan(probs, total, n, bid, v, &excl, wtot);
         if (threadIdx.x == 0) st_dev(&tile_sum[bid], tot);
     }
     if (!last_block_done(&ctl->ticket[1][0], nblocks)) return false;
-    if (threadIdx.x < 64) {                               // exclusive tile offsets: wave scan, 64 tiles a pass
+    // exclusive tile offsets: all tile totals fetched first (one round trip), then a wave scan, 64 tiles a pass, out of LDS
+    for (int t = threadIdx.x; t < n_tiles; t += SCAN_T) toff[t] = ld_dev(&tile_sum[t]);
+    __syncthreads();
+    if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         double carry = 0.0;
         for (int t0 = 0; t0 < n_tiles; t0 += 64) {
             const int t = t0 + lane;
-            const double x = t < n_tiles ? ld_dev(&tile_sum[t]) : 0.0;
+            const double x = t < n_tiles ? toff[t] : 0.0;
             double inc = x;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -432,20 +476,28 @@ __device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const fl
     }
     __syncthreads();
     const double s_last = toff[n_tiles];
-    auto c_at = [&](int32_t j) { return (ld_dev(&cdf[j]) + toff[j / SCAN_TILE]) / s_last; };
+    // the first value of tile t is its first element's p (tile-local inclusive scan) + the tile's offset
+    auto first_of = [&](int t) { return ((double)(probs[(int64_t)t * SCAN_TILE] / total) + toff[t]) / s_last; };
     for (int t = threadIdx.x; t < n_tiles; t += SCAN_T)
-        if (c_at(t * SCAN_TILE) <= u) atomicMax(&s_tile, t);
+        if (first_of(t) <= u) atomicMax(&s_tile, t);
     __syncthreads();
     const int tile = s_tile;
     if (tile < 0) {                                       // nothing <= u: index 0
-        if (threadIdx.x == 0) { pick[0] = 1; pick[1] = 0; pick[2] = (c_at(0) - u > tol) ? 1 : 0; }
+        if (threadIdx.x == 0) { pick[0] = 1; pick[1] = 0; pick[2] = (first_of(0) - u > tol) ? 1 : 0; }
     } else {
+        double v[SCAN_I], excl;
+        (void)kpp_tile_scan(probs, total, n, tile, v, &excl, wtot);
+#pragma unroll
+        for (int i = 0; i < SCAN_I; ++i) ctile[threadIdx.x * SCAN_I + i] = (excl + v[i] + toff[tile]) / s_last;
+        if (threadIdx.x == 0) ctile[SCAN_TILE] = tile + 1 < n_tiles ? first_of(tile + 1) : inf64();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < SCAN_I; ++k) {
-            const int32_t j = tile * SCAN_TILE + k * SCAN_T + threadIdx.x;
+            const int q = k * SCAN_T + threadIdx.x;
+            const int32_t j = tile * SCAN_TILE + q;
             const bool in = j < n, last = j >= n - 1;
-            const double cj = in ? c_at(j) : inf64();
-            const double cn = last ? inf64() : c_at(j + 1);
+            const double cj = in ? ctile[q] : inf64();
+            const double cn = last ? inf64() : ctile[q + 1];
             if (in && cj <= u && cn > u) {
                 pick[0] = 1; pick[1] = j + 1;
                 pick[2] = (!last && (u - cj > tol) && (cn - u > tol)) ? 1 : 0;
