@@ -228,7 +228,7 @@ __device__ __forceinline__ bool last_block_done(int32_t *ticket, int32_t partici
 //   phase 3 (last block only): the halving tree above the leaves, then the chunk roots accumulated in order.
 // `exact_max`: the per-block maxima of kpp_max_kernel are reduced here (needed when d_min still holds inf
 // entries, which are replaced by 2*max_finite); otherwise every entry is finite and no maximum is needed.
-constexpr int SUM_LEAVES = 32, TREE_LDS_NODES = 1024;
+constexpr int SUM_LEAVES = 16, TREE_LDS_NODES = 1024, SP_FLOATS = 4096;   // (16 leaves per block: 489 blocks at one million latents)
 struct SumPlan {                          // numpy's reduction tree over n float32 (host-built, see pw_build)
     const int32_t *leaf_start, *leaf_len, *node_l, *node_r, *level_off, *chunk_root;
     int n_leaves, n_levels, n_chunks;
@@ -243,7 +243,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
                                              const int32_t *__restrict__ part_inf, int n_part, int exact_max,
                                              float *__restrict__ probs, const SumPlan &pl, int bid, int nblocks,
                                              float *total_out) {
-    __shared__ float sp[SUM_LEAVES * PW_BLOCK];
+    __shared__ float sp[SP_FLOATS];
     __shared__ float smax;
     __shared__ int32_t sinf;
     const int n_leaves = pl.n_leaves;
@@ -340,7 +340,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
     const int n_levels = pl.n_levels, n_chunks = pl.n_chunks;
     const int n_nodes = pl.level_off[n_levels];
     float total = 0.0f;
-    if (n_nodes <= TREE_LDS_NODES && n_leaves + n_nodes <= SUM_LEAVES * PW_BLOCK && n_levels < 32 && n_chunks <= 64) {
+    if (n_nodes <= TREE_LDS_NODES && n_leaves + n_nodes <= SP_FLOATS && n_levels < 32 && n_chunks <= 64) {
         // small tree: one round trip brings leaves and plan into LDS, the levels then cost LDS latency only
         for (int j = threadIdx.x; j < n_leaves; j += 256) sp[j] = ld_dev(&val[j]);
         for (int j = threadIdx.x; j < n_nodes; j += 256) { s_nl[j] = pl.node_l[j]; s_nr[j] = pl.node_r[j]; }
@@ -364,7 +364,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
         // fetched by all threads first: a single thread's `total += val[chunk_root[c]]` is two dependent device-scope round trips
         // per chunk, 123 chunks at one million latents = the ~63 us this phase took per centre (kernel trace of the C4 chain,
         // round 4: 1.5 such launches per centre, 60 % of the chain's time).
-        if (n_chunks <= SUM_LEAVES * PW_BLOCK) {
+        if (n_chunks <= SP_FLOATS) {
             for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) sp[c] = ld_dev(&val[pl.chunk_root[c]]);
             __syncthreads();
             if (threadIdx.x == 0)
