@@ -204,12 +204,16 @@ def test_c2_eval_mode_per_node_primal_at_full_size(c2, request):
     for mode in (1, 0):
         _lib.check(_lib.load().geo_set_option(b"jvp_per_node", mode), "geo_set_option")
         out[mode] = edge_lengths_graph_device(ex, c2["z"], src, dst, 512).cpu().numpy()
-    np.testing.assert_array_equal(out[1], out[0])
+    np.testing.assert_array_equal(out[1], out[0])                 # all 946 059 edges, bit for bit
+    # fp64 closed form (layer-by-layer torch fp64 on the GPU: 170 s for all edges) on every 8th block of 512 edges -- eval-mode
+    # lengths do not depend on their batch, a spread sample of 118 000 edges carries the gate
     s_h, d_h = src.cpu().numpy(), dst.cpu().numpy()
-    ref64 = om.edge_lengths(c2["sd"], "batch", c2["size"], c2["z_h"][s_h], c2["z_h"][d_h], batch_size=512, training=False,
-                            dtype=torch.float64, device="cuda").numpy()
-    rel = np.abs(out[1] - ref64) / ref64
-    _record("c2_eval_mode_per_node_vs_fp64", {"edges": int(len(rel)), "frac_within": float(np.mean(rel <= TOL)),
+    pick = np.concatenate([np.arange(c * 512, min((c + 1) * 512, len(s_h))) for c in range(0, (len(s_h) + 511) // 512, 8)])
+    ref64 = om.edge_lengths(c2["sd"], "batch", c2["size"], c2["z_h"][s_h[pick]], c2["z_h"][d_h[pick]], batch_size=512,
+                            training=False, dtype=torch.float64, device="cuda").numpy()
+    rel = np.abs(out[1][pick] - ref64) / ref64
+    _record("c2_eval_mode_per_node_vs_fp64", {"edges_bit_identical": int(len(s_h)), "edges_vs_fp64": int(len(rel)),
+                                              "frac_within": float(np.mean(rel <= TOL)),
                                               "p99": float(np.quantile(rel, 0.99)), "max_rel": float(rel.max())})
     assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
     assert np.quantile(rel, 0.99) < 2e-6
