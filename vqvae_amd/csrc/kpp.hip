@@ -242,7 +242,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
                                              const uint8_t *__restrict__ is_center, const float *__restrict__ part_max,
                                              const int32_t *__restrict__ part_inf, int n_part, int exact_max,
                                              float *__restrict__ probs, const SumPlan &pl, int bid, int nblocks,
-                                             float *total_out) {
+                                             float *total_out, double *__restrict__ leaf_a = nullptr) {
     __shared__ float sp[SP_FLOATS];
     __shared__ float smax;
     __shared__ int32_t sinf;
@@ -314,9 +314,11 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
         const int len = live ? pl.leaf_len[leaf] : 0;
         const int m8 = len - (len % 8);
         float r = 0.0f;
+        double acc = 0.0;                                  // fp64 sum of the same weights: the approximate cdf of kpp_approx_draw
         if (len >= 8) {
             r = a[j];
-            for (int i = 8; i < m8; i += 8) r += a[i + j];
+            acc = (double)a[j];
+            for (int i = 8; i < m8; i += 8) { r += a[i + j]; acc += (double)a[i + j]; }
         }
         // lanes (0,1) (2,3) (4,5) (6,7) -> lanes 0,2,4,6 ; then (0,2) (4,6) -> 0,4 ; then (0,4) -> 0
         float o = __shfl_down(r, 1, 8);
@@ -324,15 +326,20 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
         o = __shfl_down(r, 2, 8);
         if ((j & 3) == 0) r += o;
         o = __shfl_down(r, 4, 8);
+        acc += __shfl_down(acc, 1, 8);
+        acc += __shfl_down(acc, 2, 8);
+        acc += __shfl_down(acc, 4, 8);
         if (j == 0) {
             r += o;
             if (len < 8) {
                 r = 0.0f;
-                for (int i = 0; i < len; ++i) r += a[i];
+                acc = 0.0;
+                for (int i = 0; i < len; ++i) { r += a[i]; acc += (double)a[i]; }
             } else {
-                for (int i = m8; i < len; ++i) r += a[i];
+                for (int i = m8; i < len; ++i) { r += a[i]; acc += (double)a[i]; }
             }
             if (live) st_dev(&val[leaf], r);
+            if (live && leaf_a) leaf_a[leaf] = acc;         // (read by the NEXT launch: a plain store)
         }
     }
     if (!last_block_done(&ctl->ticket[0][0], nblocks)) return false;
@@ -354,9 +361,29 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
         if (threadIdx.x == 0)
             for (int c = 0; c < n_chunks; ++c) total += sp[s_cr[c]];
     } else {
+        // A level's nodes eight per thread, every load of the eight in flight before the first add: one thread walking its
+        // nodes one after the other paid two dependent device-scope round trips PER NODE (15 nodes per thread on the first level
+        // at one million latents: ~37 us of the ~45 us this launch took, kernel trace of round 4).
+        constexpr int TU = 8;
         for (int lv = 0; lv < n_levels; ++lv) {
-            for (int j = pl.level_off[lv] + threadIdx.x; j < pl.level_off[lv + 1]; j += blockDim.x)
-                st_dev(&val[n_leaves + j], ld_dev(&val[pl.node_l[j]]) + ld_dev(&val[pl.node_r[j]]));
+            const int beg = pl.level_off[lv], end = pl.level_off[lv + 1];
+            for (int j0 = beg; j0 < end; j0 += (int)blockDim.x * TU) {
+                int32_t nl[TU], nr[TU];
+                float va[TU], vb[TU];
+#pragma unroll
+                for (int k = 0; k < TU; ++k) {
+                    const int j = j0 + k * (int)blockDim.x + (int)threadIdx.x;
+                    nl[k] = j < end ? pl.node_l[j] : 0;
+                    nr[k] = j < end ? pl.node_r[j] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < TU; ++k) { va[k] = ld_dev(&val[nl[k]]); vb[k] = ld_dev(&val[nr[k]]); }
+#pragma unroll
+                for (int k = 0; k < TU; ++k) {
+                    const int j = j0 + k * (int)blockDim.x + (int)threadIdx.x;
+                    if (j < end) st_dev(&val[n_leaves + j], va[k] + vb[k]);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
         }
@@ -508,6 +535,84 @@ __device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const fl
     return true;
 }
 
+// The draw on the UN-NORMALISED weights, by one workgroup (the resident chain's method, section "k-means++ chain" of DESIGN.md):
+// cdf[j] / cdf[-1] of RandomState.choice differs from sum_{i<=j} w_i / sum_i w_i by less than 2 * 2^-24 + n * 2^-52, so if u clears
+// both neighbouring steps of that approximate cdf by KPP_STEP_APPROX_MARGIN (+ tol) the index is numpy's and neither the float32
+// total nor any p_i = fl32(w_i / total) is needed: a scan over the n / 128 fp64 leaf sums of the reduction launch and ONE leaf,
+// instead of a launch over all n weights.  pick = {index, accepted}.  Declined (1-2 % of the draws) -> the exact draw runs next.
+constexpr double KPP_STEP_APPROX_MARGIN = 1.25e-7;        // > 2 * 2^-24 + n * 2^-52 up to n = 2^24
+__device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_a, const float *__restrict__ probs,
+                                                const SumPlan &pl, int32_t n, double u, double margin_rel, int32_t *pick) {
+    __shared__ double w_tot[4], t_base[256];
+    __shared__ int32_t s_thread, s_leaf;
+    __shared__ double s_leaf_e, s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_leaves = pl.n_leaves;
+    const int per = (n_leaves + 255) / 256;
+    const int l0 = tid * per, l1 = l0 + per < n_leaves ? l0 + per : n_leaves;
+    double mine = 0.0;
+    for (int l = l0; l < l1; ++l) mine += leaf_a[l];
+    double incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) w_tot[wave] = incl;
+    if (tid == 0) { s_thread = 0; pick[0] = -1; pick[1] = 0; }
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += w_tot[w];
+    t_base[tid] = base + (incl - mine);
+    if (tid == 255) s_total = base + incl;
+    __syncthreads();
+    const double S = s_total, target = u * S;
+    if (l0 < n_leaves && t_base[tid] <= target) atomicMax(&s_thread, tid);     // t_base[0] = 0 <= target
+    __syncthreads();
+    if (tid == s_thread) {                                    // the leaf inside this thread's segment
+        double e = t_base[tid];
+        int L = l0;
+        for (int l = l0; l + 1 < l1; ++l) {
+            const double nx = e + leaf_a[l];
+            if (nx <= target) { e = nx; L = l + 1; } else break;
+        }
+        s_leaf = L;
+        s_leaf_e = e;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int L = s_leaf;
+        const double leaf_e = s_leaf_e;
+        const int32_t b0 = pl.leaf_start[L];
+        const int len = pl.leaf_len[L];
+        const int i0 = 2 * lane, i1 = 2 * lane + 1;
+        const double q0 = i0 < len ? (double)probs[b0 + i0] : 0.0;
+        const double q1 = i1 < len ? (double)probs[b0 + i1] : 0.0;
+        double inc = q0 + q1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        const double c1 = leaf_e + inc, c0 = leaf_e + (inc - q1);
+        const bool le0 = i0 < len && c0 <= target, le1 = i1 < len && c1 <= target;
+        const int count = __popcll(__ballot(le0)) + __popcll(__ballot(le1));
+        // c is non-decreasing: the largest c <= target is element count-1 (or the previous leaf's end), the smallest c > target
+        // is element count
+        const int lo_i = count - 1, hi_i = count;
+        const double lo_v = __shfl((lo_i & 1) ? c1 : c0, (lo_i >> 1) & 63, 64);
+        const double hi_v = __shfl((hi_i & 1) ? c1 : c0, (hi_i >> 1) & 63, 64);
+        if (lane == 0) {
+            const double lower = count > 0 ? lo_v : leaf_e;
+            const int32_t idx = b0 + count;
+            const double margin = margin_rel * S;
+            pick[0] = idx;
+            pick[1] = (count < len && idx < n && S > 0.0 && S < 1e37 && (target - lower > margin) && (hi_v - target > margin)) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+}
+
 // scan + pick + commit: accept or decline the pick; on success also open the next solve
 __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const float *__restrict__ probs, int32_t n,
                                                          double *cdf, double *tile_sum, int n_tiles, double u,
@@ -536,7 +641,7 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
 //   DONE:  nothing (launches enqueued beyond the end of the chain).
 // Used once d_min is finite everywhere (no maximum pass needed); no launch is spent on an empty frontier.
 struct KppState {
-    int32_t mode, t, sw, stamp;        // mode 0 SOLVE, 1 DRAW, 2 DONE; centre index; sweep of its solve; solve counter
+    int32_t mode, t, sw, stamp;        // mode 0 SOLVE, 1 DRAW (approximate, one workgroup), 3 DRAW (exact), 2 DONE; centre index; sweep of its solve; solve counter
     int32_t launches, pad;
 };
 
@@ -592,7 +697,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         if ((int)blockIdx.x >= nsum) return;
         float total = 0.0f;
         if (!kpp_sum_body(ctl, dmin, argmin, d, 1, S.t, is_center, nullptr, nullptr, 0, 0, probs, pl, blockIdx.x, nsum,
-                          &total))
+                          &total, cdf))                                   // (cdf[] carries the fp64 leaf sums to the draw)
             return;
         if (threadIdx.x == 0) {
             ctl->total = total;
@@ -604,9 +709,35 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         }
         return;
     }
-    // DRAW
-    if ((int)blockIdx.x >= n_tiles) return;
+    // commit a pick: the next centre, and the opening of its solve (the next launch reads slot `next`, queue `fout`)
+    auto commit = [&](KppState &x, int32_t src) {
+        centers[S.t + 1] = src;
+        is_center[src] = 1;
+        if (S.t + 1 < it1) {
+            d[src] = 0.0;
+            fout[0] = src;
+            ctl->fcount[next][0] = 1;
+            ctl->fcount[clear][0] = 0;
+            x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
+        } else {
+            x.mode = 2; x.t = S.t + 1;
+        }
+    };
     __shared__ int32_t pick[3];
+    if (S.mode == 1) {                                                    // DRAW, first on the un-normalised weights
+        if (blockIdx.x != 0) return;
+        kpp_approx_draw(cdf, probs, pl, n, u_dev[S.t], KPP_STEP_APPROX_MARGIN + tol, pick);
+        if (threadIdx.x == 0) {
+            KppState x = S;
+            x.launches = S.launches + 1;
+            if (pick[1]) commit(x, pick[0]);
+            else x.mode = 3;                                              // u too close to a step of the approximate cdf
+            *out = x;
+        }
+        return;
+    }
+    // DRAW, exact
+    if ((int)blockIdx.x >= n_tiles) return;
     if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u_dev[S.t], tol, blockIdx.x, n_tiles, pick))
         return;
     if (threadIdx.x == 0) {
@@ -616,18 +747,7 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         if (!pick[0] || !pick[2]) {
             ctl->abort_iter = S.t; ctl->abort_reason = 2; x.mode = 2;
         } else {
-            centers[S.t + 1] = pick[1];
-            is_center[pick[1]] = 1;
-            if (S.t + 1 < it1) {                                          // the next launch reads slot `next`, queue `fout`
-                const int32_t src = pick[1];
-                d[src] = 0.0;
-                fout[0] = src;
-                ctl->fcount[next][0] = 1;
-                ctl->fcount[clear][0] = 0;
-                x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
-            } else {
-                x.mode = 2; x.t = S.t + 1;
-            }
+            commit(x, pick[1]);
         }
         *out = x;
     }
