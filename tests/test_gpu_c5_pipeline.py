@@ -30,12 +30,17 @@ def test_c5_codebook_cli_then_two_rank_prior_epoch(tmp_path):
     from vqvae_amd.scripts.build_codebook import main, make_parser
     tmp = str(tmp_path)
     sd = om.make_decoder_state(5, D, 3, norm_type="batch")
-    z = syn.gauss_latents(N_IMG * 16, D, 5).reshape(N_IMG, 4, 4, D)
+    # class-structured latents: cell (h, w) of an image of class c = 0.6 x centre[c][h][w] + unit Gaussian noise -- overlapping
+    # clusters (one connected kNN graph), but the codes carry class information the class-conditional prior can learn (round-3
+    # review: on codes of pure Gaussian latents "loss below ln K" says nothing about learning)
+    labels = np.random.RandomState(1).randint(0, 10, size=N_IMG)
+    centres = np.random.RandomState(6).randn(10, 4, 4, D).astype(np.float32)
+    z = (syn.gauss_latents(N_IMG * 16, D, 5).reshape(N_IMG, 4, 4, D) + 0.6 * centres[labels]).astype(np.float32)
     z4 = np.ascontiguousarray(np.transpose(z, (0, 3, 1, 2)))
     state = {"decoder." + k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
     torch.save({"model_state_dict": state, "epoch": 0}, os.path.join(tmp, "best.pt"))
     torch.save(torch.from_numpy(z4), os.path.join(tmp, "z.pt"))
-    torch.save(torch.from_numpy(np.random.RandomState(1).randint(0, 10, size=N_IMG).astype(np.int64)), os.path.join(tmp, "y.pt"))
+    torch.save(torch.from_numpy(labels.astype(np.int64)), os.path.join(tmp, "y.pt"))
     out = os.path.join(tmp, "codebook")
     args = make_parser().parse_args([
         "--latents_path", os.path.join(tmp, "z.pt"), "--out_dir", out, "--vae_ckpt_path", os.path.join(tmp, "best.pt"),
@@ -104,5 +109,8 @@ def test_c5_codebook_cli_then_two_rank_prior_epoch(tmp_path):
     assert len(runs[0]["train_loss"]) == steps and runs[0]["train_loss"] == runs[1]["train_loss"]     # lock-step, same losses
     assert runs[0]["arena_sum"] == runs[1]["arena_sum"]                        # identical weights on both ranks
     first, last = np.mean(runs[0]["train_loss"][:3]), np.mean(runs[0]["train_loss"][-10:])
-    assert abs(first - np.log(K)) < 0.25 and last < np.log(K) - 0.02 and runs[0]["val_loss"][0] < np.log(K)
+    print("c5 prior losses: first", first, "last", last, "val", runs[0]["val_loss"][0], "ln K", np.log(K))
+    # starts at the uniform code distribution and LEARNS the class-conditional code frequencies within the epoch (measured on the
+    # MI355X box: first 6.18, last 5.72, validation 5.68 against ln 512 = 6.24)
+    assert abs(first - np.log(K)) < 0.15 and last < np.log(K) - 0.3 and runs[0]["val_loss"][0] < np.log(K) - 0.3
     assert "token_emb.weight" in runs[0]["keys"] and "blocks.3.attn.bias" in runs[0]["keys"]            # reference state dict
