@@ -158,3 +158,29 @@ def test_pipelined_builds_equal_builds_one_after_the_other():
         np.testing.assert_array_equal(a["medoids"], b["medoids"])
         np.testing.assert_array_equal(a["assign_flat"], b["assign_flat"])
         assert a["qe"] == b["qe"]
+
+
+def test_repeated_pipelined_calls_reuse_their_streams_and_workspaces():
+    """Advisor (round 3): the workspace cache is keyed by stream handle, so every pipelined call must run on the SAME slot
+    streams (`_device.slot_streams`), not on fresh ones: the number of cached scratch buffers stays put from the second call on."""
+    from oracle import metric as om
+    from oracle import synthetic as syn
+    from vqvae_amd import _device
+    from vqvae_amd._device import device
+    from vqvae_amd.scripts.build_codebook import build_codebooks_pipelined
+    from vqvae_amd.spatial_decoder import SpatialDecoder
+    dev = device()
+    sd = om.make_decoder_state(4, 16, 1, norm_type="batch")
+    dec = SpatialDecoder(1, (256, 128, 64), 16, 28, "batch")
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(dev).train()
+    sets = [torch.from_numpy(syn.gauss_latents(3000 + 500 * i, 16, 200 + i)).to(dev) for i in range(4)]
+    kw = dict(k=12, sym="union", K=24, init="kpp", seed=42, batch_size=512)
+    first = build_codebooks_pipelined(sets, dec, depth=3, **kw)
+    n_buffers = _device.workspace_buffers()
+    streams = [s.cuda_stream for s in _device.slot_streams(dev, 3)]
+    for _ in range(3):
+        again = build_codebooks_pipelined(sets, dec, depth=3, **kw)
+        assert _device.workspace_buffers() == n_buffers
+        assert [s.cuda_stream for s in _device.slot_streams(dev, 3)] == streams
+        assert [a["qe"] for a in again] == [a["qe"] for a in first]
