@@ -268,8 +268,11 @@ typedef struct geo_decoder_desc {
 size_t geo_jvp_workspace_bytes(const geo_decoder_desc *dec, int64_t n_edges, int32_t batch_size);
 /* Workspace of geo_decoder_jvp_edges including the per-latent buffers (primal ConvT2 output and output sigmoids of every
  * latent) that decoders with fixed statistics use: the primal pass then runs once per latent instead of once per edge end
- * (what riemannian_metric.py:57-58 recomputes for every edge).  A workspace of geo_jvp_workspace_bytes() still works: the
- * call then takes the per-edge-end path. */
+ * (what riemannian_metric.py:57-58 recomputes for every edge).  With fixed statistics, latent_dim <= 16 and at least
+ * 0.75 * latent_dim edges per latent the call goes one step further and computes the decoder Jacobian once per latent (its
+ * latent_dim columns, n_nodes * latent_dim * 32 or 192 floats of this workspace), each edge end from those columns: same
+ * quantity, another summation order (within 1e-6 of the per-edge-end lengths; option jvp_node_jacobian = 0 turns it off).
+ * A workspace of geo_jvp_workspace_bytes() still works: the call then takes the per-edge-end path. */
 size_t geo_jvp_edges_workspace_bytes(const geo_decoder_desc *dec, int64_t n_nodes, int64_t n_edges, int32_t batch_size);
 int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes,
                           const int32_t *src, const int32_t *dst, int64_t n_edges, int32_t batch_size,

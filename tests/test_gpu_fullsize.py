@@ -199,12 +199,23 @@ def test_c2_eval_mode_per_node_primal_at_full_size(c2, request):
     src, dst = c2["res"]["edges"]
     dec = _decoder(c2["sd"], D, 1, c2["size"]).to(c2["dev"]).eval()
     ex = DecoderExport(dec, c2["dev"])
-    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_per_node", 1))
+    def restore():
+        _lib.load().geo_set_option(b"jvp_per_node", 1)
+        _lib.load().geo_set_option(b"jvp_node_jacobian", 1)
+    request.addfinalizer(restore)
+    _lib.check(_lib.load().geo_set_option(b"jvp_node_jacobian", 0), "geo_set_option")
     out = {}
     for mode in (1, 0):
         _lib.check(_lib.load().geo_set_option(b"jvp_per_node", mode), "geo_set_option")
         out[mode] = edge_lengths_graph_device(ex, c2["z"], src, dst, 512).cpu().numpy()
     np.testing.assert_array_equal(out[1], out[0])                 # all 946 059 edges, bit for bit
+    # default route at this size (15.8 edges per latent, d = 16): one decoder Jacobian per latent, edge ends from its columns
+    _lib.check(_lib.load().geo_set_option(b"jvp_per_node", 1), "geo_set_option")
+    _lib.check(_lib.load().geo_set_option(b"jvp_node_jacobian", 1), "geo_set_option")
+    jac = edge_lengths_graph_device(ex, c2["z"], src, dst, 512).cpu().numpy()
+    assert not np.array_equal(jac, out[1])
+    rel_routes = np.abs(jac - out[1]) / out[1]
+    assert np.quantile(rel_routes, 0.99) < 2e-6 and rel_routes.max() < 1e-4, (np.quantile(rel_routes, 0.99), rel_routes.max())
     # fp64 closed form (layer-by-layer torch fp64 on the GPU: 170 s for all edges) on every 8th block of 512 edges -- eval-mode
     # lengths do not depend on their batch, a spread sample of 118 000 edges carries the gate
     s_h, d_h = src.cpu().numpy(), dst.cpu().numpy()
@@ -212,11 +223,19 @@ def test_c2_eval_mode_per_node_primal_at_full_size(c2, request):
     ref64 = om.edge_lengths(c2["sd"], "batch", c2["size"], c2["z_h"][s_h[pick]], c2["z_h"][d_h[pick]], batch_size=512,
                             training=False, dtype=torch.float64, device="cuda").numpy()
     rel = np.abs(out[1][pick] - ref64) / ref64
+    rel_jac = np.abs(jac[pick] - ref64) / ref64
     _record("c2_eval_mode_per_node_vs_fp64", {"edges_bit_identical": int(len(s_h)), "edges_vs_fp64": int(len(rel)),
                                               "frac_within": float(np.mean(rel <= TOL)),
-                                              "p99": float(np.quantile(rel, 0.99)), "max_rel": float(rel.max())})
+                                              "p99": float(np.quantile(rel, 0.99)), "max_rel": float(rel.max()),
+                                              "per_latent_jacobian": {"frac_within": float(np.mean(rel_jac <= TOL)),
+                                                                      "p99": float(np.quantile(rel_jac, 0.99)),
+                                                                      "max_rel": float(rel_jac.max()),
+                                                                      "p99_vs_per_edge_end": float(np.quantile(rel_routes, 0.99)),
+                                                                      "max_vs_per_edge_end": float(rel_routes.max())}})
     assert np.mean(rel <= TOL) >= GATE, (int((rel > TOL).sum()), rel.max())
     assert np.quantile(rel, 0.99) < 2e-6
+    assert np.mean(rel_jac <= TOL) >= GATE, (int((rel_jac > TOL).sum()), rel_jac.max())
+    assert np.quantile(rel_jac, 0.99) < 2e-6
 
 
 def test_c2_full_chain_vs_oracle_and_dense_matrix(c2):

@@ -253,7 +253,11 @@ def test_per_node_primal_is_bit_identical_to_the_per_edge_end_path(norm, trainin
     dst_h = (src_h + 1 + r.randint(0, n_nodes - 1, n_edges)).astype(np.int32) % n_nodes
     z, src, dst = (torch.from_numpy(a).to(dev) for a in (z_h, src_h, dst_h))
     ex = DecoderExport(dec, dev)
-    request.addfinalizer(lambda: _lib.load().geo_set_option(b"jvp_per_node", 1))
+    def restore():
+        _lib.load().geo_set_option(b"jvp_per_node", 1)
+        _lib.load().geo_set_option(b"jvp_node_jacobian", 1)
+    request.addfinalizer(restore)
+    _lib.check(_lib.load().geo_set_option(b"jvp_node_jacobian", 0), "geo_set_option")   # (its own test below: not bit-identical)
     out = {}
     for mode in (1, 0):
         _lib.check(_lib.load().geo_set_option(b"jvp_per_node", mode), "geo_set_option")
@@ -264,3 +268,85 @@ def test_per_node_primal_is_bit_identical_to_the_per_edge_end_path(norm, trainin
     ref64 = om.edge_lengths(sd, norm, size, z_h[src_h], z_h[dst_h], bs, training, dtype=torch.float64).numpy()
     rel = np.abs(out[1] - ref64) / np.abs(ref64)
     assert (rel <= TOL).mean() >= 0.999, (rel <= TOL).mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm,training,d,cout,size,n_nodes,n_edges,bs,forced", [
+    ("batch", False, 16, 1, 28, 3000, 40000, 512, False),     # 13 edges per latent: the route is taken on its own
+    ("batch", False, 16, 1, 28, 3001, 20000, 512, True),      # odd latent count: the last latent is its own partner
+    ("none", True, 16, 1, 28, 777, 5001, 100, True),          # no norm layer, ragged sizes
+    ("none", False, 5, 1, 28, 1000, 9000, 64, False),         # narrow latent, small chunks
+    ("batch", False, 16, 3, 32, 1500, 6000, 512, True),       # 192-output head
+    ("group", True, 16, 1, 28, 2000, 9000, 512, True),        # GroupNorm: statistics per sample, the Jacobian still per latent
+])
+def test_per_latent_jacobian_route_matches_the_per_edge_end_path(norm, training, d, cout, size, n_nodes, n_edges, bs, forced,
+                                                                 request):
+    """Decoders with fixed statistics and d <= 16 (`jvp_node_jacobian`; SURVEY 2.1 K4'): the d unit tangents of every latent go
+    through the tangent-only pass once, and each edge end is |J(z_node) dz| from the stored columns.  A different summation
+    order from the per-edge-end path (J's columns are rounded to float32 before they are combined), so not bit-identical:
+    the route must pass the same fp64 gate as every other path, and sit within 2e-6 of the per-edge-end lengths at the 99th
+    percentile.  `forced`: option 2 (the automatic rule wants >= 0.75 d edges per latent)."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder
+    dev = device()
+    sd = om.make_decoder_state(11, d, cout, norm_type=norm)
+    dec = SpatialDecoder(cout, (256, 128, 64), d, size, norm)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(dev)
+    dec = dec.train() if training else dec.eval()
+    r = np.random.RandomState(n_edges + 1)
+    z_h = r.randn(n_nodes, d).astype(np.float32)
+    src_h = r.randint(0, n_nodes, n_edges).astype(np.int32)
+    dst_h = (src_h + 1 + r.randint(0, n_nodes - 1, n_edges)).astype(np.int32) % n_nodes
+    src_h[:3], dst_h[:3] = n_nodes - 1, [0, 1, n_nodes - 2]     # the last latent is on edges, on both sides
+    dst_h[3], src_h[3] = n_nodes - 1, 0
+    z, src, dst = (torch.from_numpy(a).to(dev) for a in (z_h, src_h, dst_h))
+    ex = DecoderExport(dec, dev)
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.geo_set_option(b"jvp_node_jacobian", 1))
+    _lib.check(lib.geo_set_option(b"jvp_node_jacobian", 0), "geo_set_option")
+    per_edge_end = edge_lengths_graph_device(ex, z, src, dst, bs).cpu().numpy()
+    _lib.check(lib.geo_set_option(b"jvp_node_jacobian", 2 if forced else 1), "geo_set_option")
+    got = edge_lengths_graph_device(ex, z, src, dst, bs).cpu().numpy()
+    assert not np.array_equal(got, per_edge_end)                 # (it did run: another summation order)
+    ref64 = om.edge_lengths(sd, norm, size, z_h[src_h], z_h[dst_h], bs, training, dtype=torch.float64).numpy()
+    rel = np.abs(got - ref64) / np.abs(ref64)
+    assert (rel <= TOL).mean() >= 0.999, (rel <= TOL).mean()
+    assert np.quantile(np.abs(got - per_edge_end) / per_edge_end, 0.99) < 2e-6
+    # the route's error against fp64 is no worse than the per-edge-end path's
+    assert np.median(rel) <= 2 * np.median(np.abs(per_edge_end - ref64) / np.abs(ref64)) + 1e-8
+
+
+@pytest.mark.gpu
+def test_per_latent_jacobian_route_is_not_taken_where_it_does_not_apply(request):
+    """Train-mode BatchNorm (the statistics are the batch's), d > 16, and graphs with few edges per latent keep the per-edge-end
+    path: same bits with the option on (1, 2) and off."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder
+    dev = device()
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.geo_set_option(b"jvp_node_jacobian", 1))
+    for norm, training, d, n_nodes, n_edges, modes in [("batch", True, 16, 1200, 30000, (1, 2)), ("batch", False, 32, 600, 30000, (1, 2)),
+                                                       ("batch", False, 16, 3000, 9000, (1,))]:
+        sd = om.make_decoder_state(3, d, 1, norm_type=norm)
+        dec = SpatialDecoder(1, (256, 128, 64), d, 28, norm)
+        dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        dec = dec.to(dev)
+        dec = dec.train() if training else dec.eval()
+        r = np.random.RandomState(d + n_edges)
+        z = torch.from_numpy(r.randn(n_nodes, d).astype(np.float32)).to(dev)
+        src_h = r.randint(0, n_nodes, n_edges).astype(np.int32)
+        dst_h = (src_h + 1 + r.randint(0, n_nodes - 1, n_edges)).astype(np.int32) % n_nodes
+        src, dst = torch.from_numpy(src_h).to(dev), torch.from_numpy(dst_h).to(dev)
+        ex = DecoderExport(dec, dev)
+        _lib.check(lib.geo_set_option(b"jvp_node_jacobian", 0), "geo_set_option")
+        off = edge_lengths_graph_device(ex, z, src, dst, 512).cpu().numpy()
+        for mode in modes:
+            _lib.check(lib.geo_set_option(b"jvp_node_jacobian", mode), "geo_set_option")
+            np.testing.assert_array_equal(edge_lengths_graph_device(ex, z, src, dst, 512).cpu().numpy(), off)

@@ -28,6 +28,7 @@ const OptionName kOptionNames[] = {
     {"jvp_back_valu", "GEO_JVP_BACK_VALU", &Options::jvp_back_valu},
     {"jvp_front_valu", "GEO_JVP_FRONT_VALU", &Options::jvp_front_valu},
     {"jvp_per_node", "GEO_JVP_PER_NODE", &Options::jvp_per_node},
+    {"jvp_node_jacobian", "GEO_JVP_NODE_JACOBIAN", &Options::jvp_node_jacobian},
 };
 Options from_environment() {
     Options o;

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
                                                    int batch, int tiles_per_group, int d, int n1,
                                                    const float *__restrict__ M01, const float *__restrict__ b01,
                                                    float *__restrict__ pre, float *__restrict__ tpre,
-                                                   double *__restrict__ partial, int want_stats) {
+                                                   double *__restrict__ partial, int want_stats, int unit_d = 0) {
+    // unit_d > 0 (per-latent Jacobians, run_node_jacobian): "edge" e is (latent pair e / unit_d, latent dimension e % unit_d);
+    // the tangent of both sides is the unit vector of that dimension instead of the latent difference.
     // [latent dimension][sample]: two neighbouring samples of a dimension are one 8-byte broadcast read feeding one packed fma
     __shared__ __attribute__((aligned(8))) float zp[DMAX][TS];
     __shared__ __attribute__((aligned(8))) float dz[DMAX][TS];
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void front_kernel(const float *__restrict__ z,
             }
         }
         zp[k][s] = side == 0 ? a : b;
-        dz[k][s] = b - a;
+        dz[k][s] = unit_d ? ((ok && k == (int)(e % unit_d)) ? 1.f : 0.f) : b - a;
         if (k == 0) valid_s[s] = ok ? 1 : 0;
     }
     for (int i = threadIdx.x; i < TS * (DMAX - d); i += 256) {      // padded latent columns: zeros, not stale LDS
@@ -1414,7 +1416,8 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
                                                        const float4 *__restrict__ gs2, float *__restrict__ sg_node = nullptr,
                                                        const int32_t *__restrict__ src = nullptr,
                                                        const int32_t *__restrict__ dst = nullptr, int64_t e_base = 0,
-                                                       int64_t n_edges = 0, int batch = 1) {
+                                                       int64_t n_edges = 0, int batch = 1, float *__restrict__ jac_node = nullptr,
+                                                       int unit_d = 0) {
     constexpr int C2 = 64, KB = 128, LDK = KB + 8, NP = NT * 32;
     __shared__ __attribute__((aligned(16))) unsigned short A3[3][2][TS][LDK];     // 52 KB, reused for the reduction
     __shared__ NormConst kc[C2];
@@ -1437,11 +1440,14 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
     const int r = lane & 31, h = lane >> 5;
     const int ss = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 16;
     // MODE 1: the latent a slot belongs to (start side: src, end side: dst; padding slots read latent 0, their result is unused)
-    auto node_of = [&](int sample) -> size_t {
+    auto edge_of = [&](int sample) -> int64_t {                   // -1: padding slot
         const int tg = tile - group * tiles_per_group;
         const int64_t e = e_base + (int64_t)(group >> 1) * batch + (int64_t)tg * TS + sample;
-        if (tg * TS + sample >= batch || e >= n_edges) return 0;
-        return (size_t)((group & 1) ? dst[e] : src[e]);
+        return (tg * TS + sample >= batch || e >= n_edges) ? -1 : e;
+    };
+    auto node_of = [&](int sample) -> size_t {
+        const int64_t e = edge_of(sample);
+        return e < 0 ? 0 : (size_t)((group & 1) ? dst[e] : src[e]);
     };
     const size_t prow = MODE == 1 ? node_of(ss) : slot0 + ss;      // row of the primal pre-activations this thread stages
     for (int kb = 0; kb < 8; ++kb) {
@@ -1505,6 +1511,12 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
     float *red = reinterpret_cast<float *>(&A3[0][0][0][0]);     // [wave 4][p|t 2][32 rows][33]
     const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
     const size_t nrow = MODE == 1 ? node_of(row) : slot0 + row;    // sg_node row: the slot's latent (1) / this latent (2)
+    // unit tangents: this slot's outputs are column e % unit_d of its latent's Jacobian, kept as jac_node[latent][dimension][NP]
+    float *jrow = nullptr;
+    if (MODE == 1 && jac_node) {
+        const int64_t e = edge_of(row);
+        if (e >= 0) jrow = jac_node + (nrow * unit_d + (size_t)(e % unit_d)) * NP;
+    }
     double sumsq = 0.0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1529,6 +1541,7 @@ __global__ __launch_bounds__(256, 2) void back_mfma_kernel(const float *__restri
                 const float sg = MODE == 1 ? sg_node[nrow * NP + o] : 1.0f / (1.0f + expf(-x));
                 if (MODE == 2) sg_node[nrow * NP + o] = sg;
                 const float j = t * sg * (1.0f - sg);
+                if (MODE == 1 && jrow) jrow[o] = j;
                 sumsq += (double)(j * j);
             }
         }
@@ -1547,6 +1560,60 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ 
         const float b = norms[(chunk * 2 + 1) * slots_per_group + within];
         len_out[e_base + i] = 0.5f * (a + b);
     }
+}
+
+// ---------------------------------------------------------------------------------- per-latent Jacobians
+// Decoders with FIXED statistics and a narrow latent (d <= 16): the decoder Jacobian J(z) (p_out x d) is a function of the
+// latent alone, and an edge end's pulled-back length is |J(z_node) (z_dst - z_src)|.  With more than ~d/2 neighbours per latent
+// it is cheaper to push the d unit tangents of every latent through the tangent-only pass ONCE (N d slots instead of 2 E) and
+// to form the edge ends from the stored columns (SURVEY 2.1 K4': "one metric tensor per latent").  The columns, not the Gram
+// matrix G = J^T J: dz^T G dz squares J's condition number into the rounding error, J dz does not, and at p_out = 16 both cost
+// d^2 multiply-adds per edge end.
+// Pseudo-edge i = (latent pair i / d, dimension i % d): start side latent 2 * pair, end side latent 2 * pair + 1 (an odd last
+// latent is its own partner: both sides then write the same column with the same bits).
+__global__ __launch_bounds__(256) void pair_edges_kernel(int64_t n_nodes, int d, int64_t n_pseudo, int32_t *__restrict__ src,
+                                                        int32_t *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pseudo; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = 2 * (i / d), b = a + 1 < n_nodes ? a + 1 : n_nodes - 1;
+        src[i] = (int32_t)a;
+        dst[i] = (int32_t)b;
+    }
+}
+
+// 16 lanes per edge (lane = output element, strided), both ends: v = J(node) dz as an fmaf chain over the latent dimensions
+// (ascending), |v| accumulated in fp64 like back_mfma_kernel's norm, length = the mean of the two ends (combine_kernel).
+__global__ __launch_bounds__(256) void jacobian_lengths_kernel(const float *__restrict__ z, const int32_t *__restrict__ src,
+                                                              const int32_t *__restrict__ dst, int64_t n_edges, int d, int p_out,
+                                                              int np, const float *__restrict__ jac_node,
+                                                              float *__restrict__ len_out) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(gid & 15);
+    int64_t e = gid >> 4;
+    const bool live = e < n_edges;
+    if (!live) e = n_edges - 1;                               // whole 16-lane teams are live or not; shuffles stay uniform
+    const int64_t a = src[e], b = dst[e];
+    float dz[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dz[k] = k < d ? z[b * d + k] - z[a * d + k] : 0.f;
+    float end_norm[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float *J = jac_node + (size_t)(side ? b : a) * d * np;
+        double sumsq = 0.0;
+        for (int o = l; o < p_out; o += 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < d) v = fmaf(dz[k], J[(size_t)k * np + o], v);
+            sumsq += (double)(v * v);
+        }
+        sumsq += __shfl_xor(sumsq, 1, 64);
+        sumsq += __shfl_xor(sumsq, 2, 64);
+        sumsq += __shfl_xor(sumsq, 4, 64);
+        sumsq += __shfl_xor(sumsq, 8, 64);
+        end_norm[side] = (float)sqrt(sumsq);
+    }
+    if (live && l == 0) len_out[e] = 0.5f * (end_norm[0] + end_norm[1]);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -1634,8 +1701,10 @@ bool make_plan(const geo_decoder_desc *dc, int64_t n_edges, int batch, Plan *p) 
 
 int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const int32_t *src, const int32_t *dst,
             const float *z_start, const float *z_end, int64_t n_edges, int32_t batch, float *len_out, void *ws,
-            size_t ws_bytes, hipStream_t stream) {
-    GEO_REQUIRE(dc && len_out && ws, "geo_decoder_jvp: null pointer");
+            size_t ws_bytes, hipStream_t stream, float *jac_node = nullptr) {
+    // jac_node != nullptr (run_node_jacobian): the edges are pseudo-edges (latent pair, latent dimension), their tangents unit
+    // vectors; the outputs go to jac_node[latent][dimension][np] and no lengths are formed
+    GEO_REQUIRE(dc && (len_out || jac_node) && ws, "geo_decoder_jvp: null pointer");
     GEO_REQUIRE(batch > 0, "geo_decoder_jvp: batch_size must be positive");
     if (n_edges == 0) return GEO_OK;
     Plan pl;
@@ -1749,6 +1818,8 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
     const bool mid_all_path = mid_split && s.n_chunks == 8 && s.opix_per_chunk == 2 && s.c1 >= 32 && mid_opt != 2;
     const bool per_node = !batch_stats && src && dst && pre2_node && mid_all_path && back_mfma &&
                           geo::options().jvp_per_node != 0;
+    GEO_REQUIRE(!jac_node || (per_node && s.d <= 16), "geo_decoder_jvp: per-latent Jacobians need the per-node primal path");
+    const int unit_d = jac_node ? s.d : 0;
     if (per_node) {
         const int64_t nt_node = (int64_t)(node_slots / TS);
         const int big_batch = (int)node_slots;                  // one group: every latent on the "start" side
@@ -1808,13 +1879,13 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 #define GEO_FRONT(DM)                                                                                              \
     front_kernel<DM><<<(unsigned)p_tiles, 256, 0, stream>>>(z, src, dst, z_start, z_end, e_base, n_edges, batch,    \
                                                             pl.tiles_per_group, s.d, s.n1, M01, b01, pre1, tpre1,   \
-                                                            part1, batch_stats ? 1 : 0)
+                                                            part1, batch_stats ? 1 : 0, unit_d)
 #define GEO_FRONT_MFMA(DM)                                                                                         \
     front_mfma_kernel<DM><<<(unsigned)p_tiles, 256, 0, stream>>>(z, src, dst, z_start, z_end, e_base, n_edges, batch, \
                                                                  pl.tiles_per_group, s.d, s.n1, M01, b01, pre1,       \
                                                                  tpre1, part1, batch_stats ? 1 : 0)
         const bool front_mfma = s.d > 16 && s.n1 % 32 == 0 && geo::options().jvp_front_valu == 0;
-        if (s.d <= 16) { if (geo::options().jvp_front_valu == 2 && s.n1 % 32 == 0) GEO_FRONT_MFMA(16); else GEO_FRONT(16); }
+        if (s.d <= 16) { if (geo::options().jvp_front_valu == 2 && s.n1 % 32 == 0 && !unit_d) GEO_FRONT_MFMA(16); else GEO_FRONT(16); }
         else if (s.d <= 32) { if (front_mfma) GEO_FRONT_MFMA(32); else GEO_FRONT(32); }
         else { if (front_mfma) GEO_FRONT_MFMA(64); else GEO_FRONT(64); }
 #undef GEO_FRONT_MFMA
@@ -1923,7 +1994,7 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
 #define GEO_BACK_T(NTV, GNV)                                                                                       \
     back_mfma_kernel<NTV, GNV, 1><<<(unsigned)p_tiles, 256, 0, stream>>>(pre2_node, tpre2, k2, 0, pl.tiles_per_group, s.co, \
                                                                          s.s_out, W3b, dc->b3, norms, gs2, sg_node, src,   \
-                                                                         dst, e_base, n_edges, batch)
+                                                                         dst, e_base, n_edges, batch, jac_node, unit_d)
         if (per_node && back_nt == 1) { if (gs2) GEO_BACK_T(1, true); else GEO_BACK_T(1, false); }
         else if (per_node) { if (gs2) GEO_BACK_T(6, true); else GEO_BACK_T(6, false); }
 #undef GEO_BACK_T
@@ -1934,10 +2005,62 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
             back_kernel<<<(unsigned)(p_slots / BACK_TS), 256, back_lds, stream>>>(
                 pre2, tpre2, k2, batch_stats ? 1 : 0, pl.slots_per_group, s.c2, s.co, s.s_out, s.pad3, W3p, dc->b3, norms);
         GEO_LAUNCH_CHECK();
-        combine_kernel<<<geo::grid_for(e_count, 256), 256, 0, stream>>>(norms, e_base, e_count, batch,
-                                                                        pl.slots_per_group, len_out);
-        GEO_LAUNCH_CHECK();
+        if (len_out) {
+            combine_kernel<<<geo::grid_for(e_count, 256), 256, 0, stream>>>(norms, e_base, e_count, batch,
+                                                                            pl.slots_per_group, len_out);
+            GEO_LAUNCH_CHECK();
+        }
     }
+    return GEO_OK;
+}
+
+// Per-latent Jacobians (kernels above): which calls take that route, its workspace, and the run.
+struct JacobianPlan {
+    int64_t n_pseudo;
+    size_t np, extra_bytes, bytes;                            // extra: pseudo-edge lists + the columns; bytes: extra + inner run
+};
+
+bool node_jacobian_plan(const geo_decoder_desc *dc, int64_t n_nodes, int64_t n_edges, int batch, JacobianPlan *jp) {
+    const geo::Options &o = geo::options();
+    Shape s;
+    if (!dc || n_nodes <= 0 || n_edges <= 0 || !make_shape(dc, &s)) return false;
+    if (o.jvp_node_jacobian == 0 || o.jvp_per_node == 0 || o.jvp_back_valu || o.jvp_mid == 1 || o.jvp_mid == 2) return false;
+    if (dc->norm == 1 && dc->bn_train) return false;          // batch statistics: the Jacobian depends on the edge's batch
+    if (s.d > 16 || s.c1 % 16 != 0 || s.c1 < 32 || s.c2 != 64 || s.n_chunks != 8 || s.opix_per_chunk != 2) return false;
+    const int back_nt = (s.p_out + 31) / 32;
+    if (back_nt != 1 && back_nt != 6) return false;
+    // worth it from ~1.5 x fewer slots (the columns pass stores and the edge pass re-reads p_out x d floats per latent)
+    if (o.jvp_node_jacobian == 1 && 4 * n_edges < 3 * n_nodes * s.d) return false;
+    jp->n_pseudo = (n_nodes + 1) / 2 * s.d;
+    if (jp->n_pseudo >= (int64_t)1 << 31) return false;
+    jp->np = (size_t)back_nt * 32;
+    Plan pl;
+    if (!make_plan(dc, jp->n_pseudo, batch, &pl)) return false;
+    const size_t node_slots = ((size_t)n_nodes + TS - 1) / TS * TS;
+    if (node_slots > (size_t)pl.chunks_per_pass * 2 * pl.slots_per_group) return false;     // per-node primal would not fit a pass
+    jp->extra_bytes = 2 * geo::align_up((size_t)jp->n_pseudo * 4) + geo::align_up((size_t)n_nodes * s.d * jp->np * 4);
+    jp->bytes = jp->extra_bytes + pl.bytes + node_bytes(s, n_nodes);
+    return true;
+}
+
+int run_node_jacobian(const geo_decoder_desc *dc, const JacobianPlan &jp, const float *z, int64_t n_nodes, const int32_t *src,
+                      const int32_t *dst, int64_t n_edges, int32_t batch, float *len_out, void *ws, size_t ws_bytes,
+                      hipStream_t stream) {
+    Shape s;
+    make_shape(dc, &s);
+    geo::Arena ar(ws, ws_bytes);
+    int32_t *psrc = ar.take<int32_t>((size_t)jp.n_pseudo), *pdst = ar.take<int32_t>((size_t)jp.n_pseudo);
+    float *jac = ar.take<float>((size_t)n_nodes * s.d * jp.np);
+    GEO_REQUIRE(jac != nullptr, "geo_decoder_jvp_edges: workspace carve failed");
+    pair_edges_kernel<<<geo::grid_for(jp.n_pseudo, 256), 256, 0, stream>>>(n_nodes, s.d, jp.n_pseudo, psrc, pdst);
+    GEO_LAUNCH_CHECK();
+    const int rc = run_jvp(dc, z, n_nodes, psrc, pdst, nullptr, nullptr, jp.n_pseudo, batch, nullptr,
+                           static_cast<char *>(ws) + ar.off, ws_bytes - ar.off, stream, jac);
+    if (rc != GEO_OK) return rc;
+    const int64_t teams = (n_edges * 16 + 255) / 256;
+    GEO_REQUIRE(teams < ((int64_t)1 << 31), "geo_decoder_jvp_edges: too many edges for one launch (%lld)", (long long)n_edges);
+    jacobian_lengths_kernel<<<(unsigned)teams, 256, 0, stream>>>(z, src, dst, n_edges, s.d, s.p_out, (int)jp.np, jac, len_out);
+    GEO_LAUNCH_CHECK();
     return GEO_OK;
 }
 
@@ -1960,13 +2083,20 @@ extern "C" size_t geo_jvp_edges_workspace_bytes(const geo_decoder_desc *dec, int
                                                 int32_t batch_size) {
     Plan pl;
     if (!dec || batch_size <= 0 || n_edges < 0 || n_nodes < 0 || !make_plan(dec, n_edges, batch_size, &pl)) return 0;
-    return pl.bytes + node_bytes(pl.sh, n_nodes);
+    const size_t per_edge_end = pl.bytes + node_bytes(pl.sh, n_nodes);
+    JacobianPlan jp;
+    if (node_jacobian_plan(dec, n_nodes, n_edges, batch_size, &jp) && jp.bytes > per_edge_end) return jp.bytes;
+    return per_edge_end;
 }
 
 extern "C" int geo_decoder_jvp_edges(const geo_decoder_desc *dec, const float *z, int64_t n_nodes, const int32_t *src,
                                      const int32_t *dst, int64_t n_edges, int32_t batch_size, float *len_out, void *ws,
                                      size_t ws_bytes, void *stream) {
     GEO_REQUIRE(n_edges == 0 || (z && src && dst && n_nodes > 0), "geo_decoder_jvp_edges: null pointer");
+    JacobianPlan jp;
+    if (batch_size > 0 && len_out && ws && node_jacobian_plan(dec, n_nodes, n_edges, batch_size, &jp) && ws_bytes >= jp.bytes)
+        return run_node_jacobian(dec, jp, z, n_nodes, src, dst, n_edges, batch_size, len_out, ws, ws_bytes,
+                                 static_cast<hipStream_t>(stream));
     return run_jvp(dec, z, n_nodes, src, dst, nullptr, nullptr, n_edges, batch_size, len_out, ws, ws_bytes,
                    static_cast<hipStream_t>(stream));
 }
