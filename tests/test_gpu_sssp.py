@@ -269,6 +269,29 @@ def test_device_kpp_chain_equals_host_draw_and_oracle():
     assert kpp_initialization_graph(W, 20, seed=3) == ok.kpp_initialization_graph(W, 20, seed=3)
 
 
+@pytest.mark.parametrize("n", [150_011, 163_840])
+def test_device_kpp_chain_at_large_n_equals_host_draw(n):
+    """Above ~133 000 nodes numpy's reduction tree no longer fits the sum launch's LDS: every numpy buffer (8 192 elements) is
+    reduced by the last of its four blocks, the buffer sums added in order by the last of those (kpp_sum_body, large n).  Same
+    medoids / assignments / QE as the chain whose draws numpy itself makes on the host; 150 011 has a ragged last buffer (2 555
+    elements, its own tree), 163 840 = 20 full buffers."""
+    import os
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
+    from vqvae_amd.geo.knn_graph_optimized import knn_graph_device
+    G, _, _ = knn_graph_device(torch.from_numpy(latents(n, 8, 5)).to(device()), 8, mode="distance", sym="union")
+    med_d, assign_d, qe_d = fit_kmedoids_optimized(G, K=48, init="kpp", seed=11)
+    os.environ["GEO_KPP_HOST_DRAW"] = "1"
+    try:
+        med_h, assign_h, qe_h = fit_kmedoids_optimized(G, K=48, init="kpp", seed=11)
+    finally:
+        os.environ.pop("GEO_KPP_HOST_DRAW")
+    np.testing.assert_array_equal(med_d, med_h)
+    np.testing.assert_array_equal(assign_d, assign_h)
+    assert qe_d == qe_h and len(set(med_d.tolist())) == 48
+
+
 def test_kpp_small_and_degenerate_graphs():
     """Reference tests/test_kmeans_optimized.py:39-79,175-214 shapes: complete graphs, K=1, K>N, disconnected."""
     from oracle import kmedoids as ok

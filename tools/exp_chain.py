@@ -1,11 +1,13 @@
 """k-means++ chain: log of the geo_kpp_chain calls (segment, budget, sweeps used, aborts) and total time.
-usage: exp_chain.py [gauss|swiss] [N] [K]"""
+usage: exp_chain.py [gauss|swiss] [N] [K] [path/to/another/libgeo_hip.so]"""
 import sys, os, time, ctypes, contextlib, io, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vqvae_amd.geo.knn_graph_optimized import knn_graph_device
 import vqvae_amd.geo.kmeans_optimized as km
 from vqvae_amd import _lib
+if len(sys.argv) > 4:
+    _lib.LIB_PATH = sys.argv[4]
 import bench
 dev = torch.device('cuda', 0)
 kind = sys.argv[1] if len(sys.argv) > 1 else 'gauss'

@@ -231,9 +231,16 @@ __device__ __forceinline__ bool last_block_done(int32_t *ticket, int32_t partici
 constexpr int SUM_LEAVES = 16, TREE_LDS_NODES = 1024, SP_FLOATS = 4096;   // (16 leaves per block: 489 blocks at one million latents)
 struct SumPlan {                          // numpy's reduction tree over n float32 (host-built, see pw_build)
     const int32_t *leaf_start, *leaf_len, *node_l, *node_r, *level_off, *chunk_root;
-    int n_leaves, n_levels, n_chunks;
+    int n_leaves, n_levels, n_chunks, n_nodes;
     float *val;
+    // large n: the tree of ONE numpy buffer (<= 8 192 elements, <= 128 leaves) in local ids -- [0] a full buffer, [1] the last
+    // (partial) one, CPLAN_INTS ints each: {leaves, nodes, levels, root, level_off[12], node_l[128], node_r[128]} -- a ticket per
+    // buffer and the buffers' sums
+    const int32_t *cplan;
+    int32_t *chunk_ticket;
+    float *chunk_val;
 };
+constexpr int CPLAN_MAX_LEAVES = 128, CPLAN_INTS = 16 + 2 * CPLAN_MAX_LEAVES;
 
 // Block `bid` of `nblocks`.  Returns true (for all its threads) in the block that finished the tree; its thread 0
 // then holds the total in *total_out.
@@ -342,12 +349,12 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
             if (live && leaf_a) leaf_a[leaf] = acc;         // (read by the NEXT launch: a plain store)
         }
     }
-    if (!last_block_done(&ctl->ticket[0][0], nblocks)) return false;
     __shared__ int32_t s_nl[TREE_LDS_NODES], s_nr[TREE_LDS_NODES], s_lo[32], s_cr[64];
     const int n_levels = pl.n_levels, n_chunks = pl.n_chunks;
-    const int n_nodes = pl.level_off[n_levels];
+    const int n_nodes = pl.n_nodes;
     float total = 0.0f;
     if (n_nodes <= TREE_LDS_NODES && n_leaves + n_nodes <= SP_FLOATS && n_levels < 32 && n_chunks <= 64) {
+        if (!last_block_done(&ctl->ticket[0][0], nblocks)) return false;
         // small tree: one round trip brings leaves and plan into LDS, the levels then cost LDS latency only
         for (int j = threadIdx.x; j < n_leaves; j += 256) sp[j] = ld_dev(&val[j]);
         for (int j = threadIdx.x; j < n_nodes; j += 256) { s_nl[j] = pl.node_l[j]; s_nr[j] = pl.node_r[j]; }
@@ -361,43 +368,40 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
         if (threadIdx.x == 0)
             for (int c = 0; c < n_chunks; ++c) total += sp[s_cr[c]];
     } else {
-        // A level's nodes eight per thread, every load of the eight in flight before the first add: one thread walking its
-        // nodes one after the other paid two dependent device-scope round trips PER NODE (15 nodes per thread on the first level
-        // at one million latents: ~37 us of the ~45 us this launch took, kernel trace of round 4).
-        constexpr int TU = 8;
-        for (int lv = 0; lv < n_levels; ++lv) {
-            const int beg = pl.level_off[lv], end = pl.level_off[lv + 1];
-            for (int j0 = beg; j0 < end; j0 += (int)blockDim.x * TU) {
-                int32_t nl[TU], nr[TU];
-                float va[TU], vb[TU];
-#pragma unroll
-                for (int k = 0; k < TU; ++k) {
-                    const int j = j0 + k * (int)blockDim.x + (int)threadIdx.x;
-                    nl[k] = j < end ? pl.node_l[j] : 0;
-                    nr[k] = j < end ? pl.node_r[j] : 0;
-                }
-#pragma unroll
-                for (int k = 0; k < TU; ++k) { va[k] = ld_dev(&val[nl[k]]); vb[k] = ld_dev(&val[nr[k]]); }
-#pragma unroll
-                for (int k = 0; k < TU; ++k) {
-                    const int j = j0 + k * (int)blockDim.x + (int)threadIdx.x;
-                    if (j < end) st_dev(&val[n_leaves + j], va[k] + vb[k]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // Large n: the tree is a forest -- one halving tree per numpy buffer of 8 192 elements, whose sums are then added in order.
+        // The LAST of the (four) blocks of a buffer reduces that buffer's <= 128 leaf sums in LDS (one device-scope round trip for
+        // the leaves, the levels at LDS latency) and publishes the buffer's sum; the last buffer to finish adds the sums in order.
+        // Round 4 walked all levels of all buffers in the launch's last block through global memory: six levels x (index loads ->
+        // dependent device-scope value loads -> stores -> barrier), ~18 of the ~33 us this launch took per centre at one million
+        // latents (kernel trace of the C4 chain).
+        constexpr int LPC = NP_BUFSIZE / PW_BLOCK, BPC = LPC / SUM_LEAVES;      // leaves / blocks of a full buffer
+        const int chunk = l0 / LPC < n_chunks - 1 ? l0 / LPC : n_chunks - 1;
+        const int participants = chunk < n_chunks - 1 ? BPC : nblocks - (n_chunks - 1) * BPC;
+        if (!last_block_done(&pl.chunk_ticket[chunk], participants)) return false;
+        const int32_t *cp = pl.cplan + (chunk == n_chunks - 1 ? CPLAN_INTS : 0);
+        const int cl = cp[0], cn = cp[1], clv = cp[2], croot = cp[3];
+        const int first_leaf = chunk * LPC;
+        for (int j = threadIdx.x; j < cl; j += 256) sp[j] = ld_dev(&val[first_leaf + j]);
+        for (int j = threadIdx.x; j < cn; j += 256) { s_nl[j] = cp[16 + j]; s_nr[j] = cp[16 + CPLAN_MAX_LEAVES + j]; }
+        if ((int)threadIdx.x <= clv) s_lo[threadIdx.x] = cp[4 + threadIdx.x];
+        __syncthreads();
+        for (int lv = 0; lv < clv; ++lv) {
+            for (int j = s_lo[lv] + threadIdx.x; j < s_lo[lv + 1]; j += 256) sp[cl + j] = sp[s_nl[j]] + sp[s_nr[j]];
             __syncthreads();
         }
-        // The chunk roots are accumulated IN ORDER by one thread (numpy adds its 8 192-element buffers one after the other) -- but
-        // fetched by all threads first: a single thread's `total += val[chunk_root[c]]` is two dependent device-scope round trips
-        // per chunk, 123 chunks at one million latents = the ~63 us this phase took per centre (kernel trace of the C4 chain,
-        // round 4: 1.5 such launches per centre, 60 % of the chain's time).
+        if (threadIdx.x == 0) {
+            st_dev(&pl.chunk_val[chunk], sp[croot]);
+            st_dev(&pl.chunk_ticket[chunk], 0);                 // (every block of the buffer has drawn its ticket)
+        }
+        if (!last_block_done(&ctl->ticket[0][0], n_chunks)) return false;
+        // numpy adds its buffers one after the other: fetched by all threads, added in order by one
         if (n_chunks <= SP_FLOATS) {
-            for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) sp[c] = ld_dev(&val[pl.chunk_root[c]]);
+            for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) sp[c] = ld_dev(&pl.chunk_val[c]);
             __syncthreads();
             if (threadIdx.x == 0)
                 for (int c = 0; c < n_chunks; ++c) total += sp[c];
         } else if (threadIdx.x == 0) {
-            for (int c = 0; c < n_chunks; ++c) total += ld_dev(&val[pl.chunk_root[c]]);
+            for (int c = 0; c < n_chunks; ++c) total += ld_dev(&pl.chunk_val[c]);
         }
     }
     *total_out = total;
@@ -569,15 +573,32 @@ __device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_
     const double S = s_total, target = u * S;
     if (l0 < n_leaves && t_base[tid] <= target) atomicMax(&s_thread, tid);     // t_base[0] = 0 <= target
     __syncthreads();
-    if (tid == s_thread) {                                    // the leaf inside this thread's segment
-        double e = t_base[tid];
-        int L = l0;
-        for (int l = l0; l + 1 < l1; ++l) {
-            const double nx = e + leaf_a[l];
-            if (nx <= target) { e = nx; L = l + 1; } else break;
+    if (wave == 0) {
+        // the leaf inside the picked thread's segment: the segment's leaf sums fetched by the lanes together (round 4 walked them
+        // in one thread behind a data-dependent exit, a cache round trip per leaf), scanned, and counted while they stay <= target
+        // -- the last leaf of the segment is never stepped over (the next segment's base is > target)
+        const int st = s_thread;
+        const int sl0 = st * per, sl1 = sl0 + per < n_leaves ? sl0 + per : n_leaves;
+        double carry = t_base[st];
+        int L = sl0;
+        double e = carry;
+        for (int p0 = sl0; p0 < sl1; p0 += 64) {
+            const int l = p0 + lane;
+            const double x = l < sl1 ? leaf_a[l] : 0.0;
+            double inc = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            const double incl = carry + inc;
+            const bool ok = l + 1 < sl1 && incl <= target;
+            const int cnt = __popcll(__ballot(ok));
+            if (cnt > 0) { e = __shfl(incl, cnt - 1, 64); L = p0 + cnt; }
+            if (cnt < 64) break;                                  // (uniform: cnt comes from a ballot)
+            carry = __shfl(incl, 63, 64);
         }
-        s_leaf = L;
-        s_leaf_e = e;
+        if (lane == 0) { s_leaf = L; s_leaf_e = e; }
     }
     __syncthreads();
     if (wave == 0) {
@@ -1301,7 +1322,7 @@ struct KppWs {
 
 size_t plan_ints_bound(int32_t n) {
     const size_t leaves = (size_t)n / 64 + (size_t)n / NP_BUFSIZE + 16;      // leaves have >= 64 elements except per chunk tails
-    return 6 * leaves + 64;
+    return 6 * leaves + 64 + 2 * CPLAN_INTS + (size_t)n / NP_BUFSIZE + 1;      // + the per-buffer plans and tickets
 }
 
 bool carve(void *ws, size_t ws_bytes, int32_t n, KppWs *o) {
@@ -1394,7 +1415,34 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     for (int k = 0; k < M; ++k) blob.push_back(fix(pp.node_r[order[k]]));
     for (int lv = 0; lv <= max_level; ++lv) blob.push_back(level_off[lv]);
     for (int32_t r : roots_raw) blob.push_back(fix(r));
-    GEO_REQUIRE(blob.size() <= w.plan_ints && (size_t)(L + M) <= w.plan_ints, "geo_kpp_chain: reduction plan overflow");
+    // the tree of one buffer in local ids (kpp_sum_body, large n): a full buffer and the last one; then one ticket per buffer
+    const size_t cplan_at = blob.size();
+    for (int kind = 0; kind < 2; ++kind) {
+        const int32_t len = kind == 0 ? (n < NP_BUFSIZE ? n : NP_BUFSIZE) : n - ((int32_t)roots_raw.size() - 1) * NP_BUFSIZE;
+        PwPlan lp;
+        int lv_root;
+        const int32_t root = pw_build(lp, 0, len, &lv_root);
+        const int cl = (int)lp.leaf_start.size(), cn = (int)lp.node_l.size();
+        GEO_REQUIRE(cl <= CPLAN_MAX_LEAVES && cn < CPLAN_MAX_LEAVES && lv_root <= 11, "geo_kpp_chain: buffer tree too large (%d leaves)", cl);
+        std::vector<int32_t> loff(lv_root + 2, 0), lpos(cn);
+        for (int j = 0; j < cn; ++j) loff[lp.node_level[j]]++;
+        {
+            int run = 0;
+            for (int lv = 1; lv <= lv_root; ++lv) { const int c = loff[lv]; loff[lv - 1] = run; run += c; }
+            loff[lv_root] = run;
+            std::vector<int32_t> cursor(loff.begin(), loff.end());
+            for (int j = 0; j < cn; ++j) lpos[j] = cursor[lp.node_level[j] - 1]++;
+        }
+        auto lfix = [&](int32_t id) { return id >= 0 ? id : cl + lpos[-id - 1]; };
+        std::vector<int32_t> cpv(CPLAN_INTS, 0);
+        cpv[0] = cl; cpv[1] = cn; cpv[2] = lv_root; cpv[3] = lfix(root);
+        for (int lv = 0; lv <= lv_root; ++lv) cpv[4 + lv] = loff[lv];
+        for (int j = 0; j < cn; ++j) { cpv[16 + lpos[j]] = lfix(lp.node_l[j]); cpv[16 + CPLAN_MAX_LEAVES + lpos[j]] = lfix(lp.node_r[j]); }
+        blob.insert(blob.end(), cpv.begin(), cpv.end());
+    }
+    const size_t ticket_at = blob.size();
+    blob.insert(blob.end(), roots_raw.size(), 0);
+    GEO_REQUIRE(blob.size() <= w.plan_ints && (size_t)(L + M) + roots_raw.size() <= w.plan_ints, "geo_kpp_chain: reduction plan overflow");
     GEO_HIP_CHECK(hipMemcpyAsync(w.plan_blob, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DevPlan &dp = w.plan;
     dp.n_leaves = L; dp.n_nodes = M; dp.n_levels = max_level; dp.n_chunks = (int)roots_raw.size();
@@ -1423,6 +1471,8 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
     spl.leaf_start = dp.leaf_start; spl.leaf_len = dp.leaf_len; spl.node_l = dp.node_l; spl.node_r = dp.node_r;
     spl.level_off = dp.level_off; spl.chunk_root = dp.chunk_root;
     spl.n_leaves = dp.n_leaves; spl.n_levels = dp.n_levels; spl.n_chunks = dp.n_chunks; spl.val = dp.val;
+    spl.n_nodes = M;
+    spl.cplan = w.plan_blob + cplan_at; spl.chunk_ticket = w.plan_blob + ticket_at; spl.chunk_val = dp.val + L + M;
     const bool have_u = n_centers_total > 1 && u_host;
     if (sweeps_per_solve <= 0 && have_u)
         GEO_HIP_CHECK(hipMemcpyAsync(w.u_dev, u_host, (size_t)(n_centers_total - 1) * sizeof(double), hipMemcpyHostToDevice, s));

@@ -94,21 +94,33 @@ def _next_center(rng, N: int, d_min: np.ndarray, centers: List[int]) -> Optional
 def _draw_with_u(N: int, d_min: np.ndarray, centers: List[int], u: float):
     """The draw of kmeans_optimized.py:47-61 with the uniform deviate given: RandomState.choice(N, p=probs) is
     cdf = cumsum(float64(p)); cdf /= cdf[-1]; searchsorted(cdf, random_sample(), 'right').  Returns None when
-    the weights are degenerate (sum == 0), which the caller resolves with the reference's fallback."""
+    the weights are degenerate (sum == 0), which the caller resolves with the reference's fallback.
+    Same values with fewer passes over the N entries (this runs when the device declines a draw, about once per chain
+    at a million latents): no copy when every distance is finite, the cumulative sum taken in float64 directly, and
+    the division by cdf[-1] -- monotone, so it cannot reorder the entries -- applied only around the answer."""
     finite = np.isfinite(d_min)
-    if finite.any():
+    if finite.all():
+        safe = d_min
+    elif finite.any():
         safe = np.where(finite, d_min, np.max(d_min[finite]) * 2.0)
     else:
         safe = np.ones_like(d_min)
-    probs = safe ** 2
+    probs = safe * safe                                   # == safe ** 2 (numpy squares by multiplying)
     probs[centers] = 0.0
     total = probs.sum()
     if not total > 0:
         return None
     probs /= total
-    cdf = probs.astype(np.float64).cumsum()
-    cdf /= cdf[-1]
-    return int(cdf.searchsorted(u, side="right"))
+    cdf = np.cumsum(probs, dtype=np.float64)              # == probs.astype(float64).cumsum()
+    last = cdf[-1]
+    # searchsorted(cdf / last, u, 'right') = number of entries with cdf[j] / last <= u: start from the position in the
+    # undivided array and settle it with the exact quotients of its neighbours
+    j = int(cdf.searchsorted(u * last, side="right"))
+    while j < N and cdf[j] / last <= u:
+        j += 1
+    while j > 0 and not (cdf[j - 1] / last <= u):
+        j -= 1
+    return j
 
 
 def _kpp_chain_host(G: DeviceCSR, K: int, seed: int, absorb_last: bool):
