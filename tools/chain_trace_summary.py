@@ -11,11 +11,13 @@ for path in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort()
 a = np.array(rows, dtype=np.int64)
-# the chain of the LAST repetition: a gap > 5 ms separates repetitions
+# a gap > 5 ms separates repetitions / chain calls
 gaps_all = a[1:, 0] - a[:-1, 1]
 cut = np.nonzero(gaps_all > 5_000_000)[0]
-if len(cut):
-    a = a[cut[-1] + 1:]
+if len(cut):                                  # the longest run of launches without such a gap
+    bounds = np.concatenate([[0], cut + 1, [len(a)]])
+    k = int(np.argmax(np.diff(bounds)))
+    a = a[bounds[k]:bounds[k + 1]]
 dur = (a[:, 1] - a[:, 0]) / 1e3
 gap = np.concatenate([[0], (a[1:, 0] - a[:-1, 1]) / 1e3])
 print("launches", len(a), "span ms %.2f" % ((a[-1, 1] - a[0, 0]) / 1e6), "sum of durations ms %.2f" % (dur.sum() / 1e3),

@@ -302,8 +302,10 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
                 float x = xs[k];
                 if (fuse_finish && dds[k] < inf64()) {             // reached by the solve of centre `pos`
                     const float xd = (float)dds[k];
-                    if (xd < x) { x = xd; dmin[i] = xd; argmin[i] = pos; }
-                    d[i] = inf64();
+                    // (agent-scope stores: the launch's last block reads d_min of the picked leaf and opens the next solve
+                    // with a store to d[] -- a plain store could still sit in another XCD's L2 then; only touched nodes pay)
+                    if (xd < x) { x = xd; st_dev(&dmin[i], xd); argmin[i] = pos; }
+                    st_dev(&d[i], inf64());
                 }
                 const float safe = any_finite ? (x < inf32() ? x : sub) : 1.0f;
                 const float p = ics[k] ? 0.0f : safe * safe;
@@ -346,7 +348,7 @@ __device__ __forceinline__ bool kpp_sum_body(KppCtl *ctl, float *__restrict__ dm
                 for (int i = m8; i < len; ++i) { r += a[i]; acc += (double)a[i]; }
             }
             if (live) st_dev(&val[leaf], r);
-            if (live && leaf_a) leaf_a[leaf] = acc;         // (read by the NEXT launch: a plain store)
+            if (live && leaf_a) st_dev(&leaf_a[leaf], acc);  // (read by this launch's last block)
         }
     }
     __shared__ int32_t s_nl[TREE_LDS_NODES], s_nr[TREE_LDS_NODES], s_lo[32], s_cr[64];
@@ -545,7 +547,10 @@ __device__ __forceinline__ bool kpp_draw_body(KppCtl *ctl, float total, const fl
 // total nor any p_i = fl32(w_i / total) is needed: a scan over the n / 128 fp64 leaf sums of the reduction launch and ONE leaf,
 // instead of a launch over all n weights.  pick = {index, accepted}.  Declined (1-2 % of the draws) -> the exact draw runs next.
 constexpr double KPP_STEP_APPROX_MARGIN = 1.25e-7;        // > 2 * 2^-24 + n * 2^-52 up to n = 2^24
-__device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_a, const float *__restrict__ probs,
+// Runs in the LAST block of the reduction launch itself (round 4 spent a launch of its own on it, ~12 us per centre): the leaf sums
+// come through agent-scope loads, and the weights of the picked leaf are formed again from d_min (agent-scope loads: the entries
+// this launch improved were stored at that scope) -- `probs` of that leaf may still sit in another XCD's L2.
+__device__ __forceinline__ void kpp_approx_draw(const double *leaf_a, const float *dmin, const uint8_t *__restrict__ is_center,
                                                 const SumPlan &pl, int32_t n, double u, double margin_rel, int32_t *pick) {
     __shared__ double w_tot[4], t_base[256];
     __shared__ int32_t s_thread, s_leaf;
@@ -555,7 +560,7 @@ __device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_
     const int per = (n_leaves + 255) / 256;
     const int l0 = tid * per, l1 = l0 + per < n_leaves ? l0 + per : n_leaves;
     double mine = 0.0;
-    for (int l = l0; l < l1; ++l) mine += leaf_a[l];
+    for (int l = l0; l < l1; ++l) mine += ld_dev(&leaf_a[l]);
     double incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -584,7 +589,7 @@ __device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_
         double e = carry;
         for (int p0 = sl0; p0 < sl1; p0 += 64) {
             const int l = p0 + lane;
-            const double x = l < sl1 ? leaf_a[l] : 0.0;
+            const double x = l < sl1 ? ld_dev(&leaf_a[l]) : 0.0;
             double inc = x;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -607,8 +612,12 @@ __device__ __forceinline__ void kpp_approx_draw(const double *__restrict__ leaf_
         const int32_t b0 = pl.leaf_start[L];
         const int len = pl.leaf_len[L];
         const int i0 = 2 * lane, i1 = 2 * lane + 1;
-        const double q0 = i0 < len ? (double)probs[b0 + i0] : 0.0;
-        const double q1 = i1 < len ? (double)probs[b0 + i1] : 0.0;
+        auto weight = [&](int32_t i) -> double {               // kpp_sum_body's p of entry i (every d_min finite in this mode)
+            const float x = ld_dev(&dmin[i]);
+            return is_center[i] ? 0.0 : (double)(x * x);
+        };
+        const double q0 = i0 < len ? weight(b0 + i0) : 0.0;
+        const double q1 = i1 < len ? weight(b0 + i1) : 0.0;
         double inc = q0 + q1;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -657,12 +666,13 @@ __global__ __launch_bounds__(SCAN_T) void kpp_draw_kernel(KppCtl *ctl, const flo
 // not wait for every centre.  So every launch runs "the next step": it reads the state the previous launch left
 // (double buffered by launch parity: all blocks read S[parity], one thread writes S[parity ^ 1]) and either
 //   SOLVE: relaxes the current frontier -- or, when that is empty, the solve has converged and the SAME launch
-//          applies it and sums the draw weights (kpp_sum_body); the last centre is only applied;
-//   DRAW:  scans, picks and commits the next centre and opens its solve (kpp_draw_body);
+//          applies it, sums the draw weights (kpp_sum_body) and its last block draws on the un-normalised weights
+//          (kpp_approx_draw), commits the next centre and opens its solve; the last centre is only applied;
+//   DRAW:  only when that draw declined (u within 1.25e-7 of a step): the exact scan, pick and commit (kpp_draw_body);
 //   DONE:  nothing (launches enqueued beyond the end of the chain).
 // Used once d_min is finite everywhere (no maximum pass needed); no launch is spent on an empty frontier.
 struct KppState {
-    int32_t mode, t, sw, stamp;        // mode 0 SOLVE, 1 DRAW (approximate, one workgroup), 3 DRAW (exact), 2 DONE; centre index; sweep of its solve; solve counter
+    int32_t mode, t, sw, stamp;        // mode 0 SOLVE (+ sum + approximate draw when converged), 3 DRAW (exact), 2 DONE; centre index; sweep of its solve; solve counter
     int32_t launches, pad;
 };
 
@@ -688,6 +698,21 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         if (blockIdx.x == 0 && threadIdx.x == 0) { KppState x = S; x.mode = 2; *out = x; }
         return;
     }
+    // commit a pick: the next centre, and the opening of its solve (the next launch reads slot `next`, queue `fout`)
+    auto commit = [&](KppState &x, int32_t src) {
+        centers[S.t + 1] = src;
+        is_center[src] = 1;
+        if (S.t + 1 < it1) {
+            st_dev(&d[src], 0.0);                          // (agent scope: another block of this launch may have reset d[src])
+            fout[0] = src;
+            ctl->fcount[next][0] = 1;
+            ctl->fcount[clear][0] = 0;
+            x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
+        } else {
+            x.mode = 2; x.t = S.t + 1;
+        }
+    };
+    __shared__ int32_t pick[3];
     if (S.mode == 0) {
         if (cnt > 0) {                                                    // one more sweep of this solve
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -720,44 +745,21 @@ __global__ __launch_bounds__(256) void kpp_step_kernel(KppCtl *ctl, KppState *st
         if (!kpp_sum_body(ctl, dmin, argmin, d, 1, S.t, is_center, nullptr, nullptr, 0, 0, probs, pl, blockIdx.x, nsum,
                           &total, cdf))                                   // (cdf[] carries the fp64 leaf sums to the draw)
             return;
+        // ... and the draw, first on the un-normalised weights, by this last block
+        kpp_approx_draw(cdf, dmin, is_center, pl, n, u_dev[S.t], KPP_STEP_APPROX_MARGIN + tol, pick);
         if (threadIdx.x == 0) {
             ctl->total = total;
             ctl->ticket[0][0] = 0;
             KppState x = S;
-            x.mode = 1; x.launches = S.launches + 1;
-            if (!(total > 0.0f)) { ctl->abort_iter = S.t; ctl->abort_reason = 3; x.mode = 2; }
-            *out = x;
-        }
-        return;
-    }
-    // commit a pick: the next centre, and the opening of its solve (the next launch reads slot `next`, queue `fout`)
-    auto commit = [&](KppState &x, int32_t src) {
-        centers[S.t + 1] = src;
-        is_center[src] = 1;
-        if (S.t + 1 < it1) {
-            d[src] = 0.0;
-            fout[0] = src;
-            ctl->fcount[next][0] = 1;
-            ctl->fcount[clear][0] = 0;
-            x.mode = 0; x.t = S.t + 1; x.sw = 0; x.stamp = S.stamp + 1;
-        } else {
-            x.mode = 2; x.t = S.t + 1;
-        }
-    };
-    __shared__ int32_t pick[3];
-    if (S.mode == 1) {                                                    // DRAW, first on the un-normalised weights
-        if (blockIdx.x != 0) return;
-        kpp_approx_draw(cdf, probs, pl, n, u_dev[S.t], KPP_STEP_APPROX_MARGIN + tol, pick);
-        if (threadIdx.x == 0) {
-            KppState x = S;
             x.launches = S.launches + 1;
-            if (pick[1]) commit(x, pick[0]);
+            if (!(total > 0.0f)) { ctl->abort_iter = S.t; ctl->abort_reason = 3; x.mode = 2; }
+            else if (pick[1]) commit(x, pick[0]);
             else x.mode = 3;                                              // u too close to a step of the approximate cdf
             *out = x;
         }
         return;
     }
-    // DRAW, exact
+    // DRAW, exact (mode 3)
     if ((int)blockIdx.x >= n_tiles) return;
     if (!kpp_draw_body(ctl, ctl->total, probs, n, cdf, tile_sum, n_tiles, u_dev[S.t], tol, blockIdx.x, n_tiles, pick))
         return;
@@ -1512,11 +1514,11 @@ extern "C" int geo_kpp_chain(const int32_t *indptr, const int32_t *indices, cons
             GEO_HIP_CHECK(hipMemcpyAsync(&hc, w.ctl, sizeof(KppCtl), hipMemcpyDeviceToHost, s));
             GEO_HIP_CHECK(hipStreamSynchronize(s));
             if (hs.mode == 2 || hc.abort_iter >= 0) break;
-            // launches still needed ~ centres left x launches per centre so far (+10 %), at most 1024 per round trip
+            // launches still needed ~ centres left x launches per centre so far (+10 %), at most 512 per round trip
             const int32_t done_centres = hs.t - ia > 0 ? hs.t - ia : 1;
             const double per_centre = (double)hs.launches / done_centres;
             const double est = (double)(ib - hs.t) * per_centre * 1.1 + 8.0;
-            batch = est > 1024.0 ? 1024 : (int32_t)est;
+            batch = est > 512.0 ? 512 : (int32_t)est;      // (launches enqueued behind a declined draw run empty: ~13 us each)
             t_now = hs.t;
             GEO_REQUIRE(launched < ((int64_t)1 << 31), "geo_kpp_chain: step kernel did not finish");
         }
