@@ -340,8 +340,9 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits.  x_i.x_j ~ hi_i.hi_j + hi_i.lo_j + lo_i.hi_j on
 // v_mfma_f32_32x32x16_bf16 (three 32-cycle instructions per 32 x 32 pairs and 16 dimensions, against DP/2+1 64-cycle
 // float32 ones); the dropped lo.lo term and the parts' own roundings are below 2^-16 |x_i||x_j|, which the caller's eps
-// (relative to |x_i|^2 + |x_j|^2) covers.  The accumulator starts at |x_j|^2 (1 - eps) - u_i, so the sign of the result
-// is the test, as in knn_scan_kernel; the kept pairs take the same queue.
+// (relative to |x_i|^2 + |x_j|^2) covers.  The accumulator starts at -u_i; a lane's 16 entries belong to one candidate j, so
+// the test is acc < -|x_j|^2 (1 - eps): the lane's minimum against one value (round 4; before, |x_j|^2 entered through a fourth
+// MFMA and the sign was the test, as in knn_scan_kernel).  The kept pairs take the same queue.
 typedef __bf16 bf16x8k __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
@@ -373,9 +374,11 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     constexpr int KST = DPB / 16;                              // MFMA k-steps
     constexpr int ROWB = 2 * DPB * 2 + 16;                     // bytes per candidate in LDS: hi, lo, 16 of padding (banks)
     __shared__ __attribute__((aligned(16))) unsigned char Ts[2][SCAN_CT * ROWB];
-    // |x_j|^2 (1 - eps) rounded down to float32, as three exact bf16 parts: it enters the accumulator through one more MFMA
-    // (A = ones in k = 0..2, B = the parts) instead of 32 vector subtractions per 2 048 pairs
-    __shared__ uint2 Nb[2][SCAN_CT];
+    // -|x_j|^2 (1 - eps), |.| rounded down to float32: a lane's accumulator entries all belong to ONE candidate (its column), so
+    // "distance below the threshold" is acc < -n_j with acc = -u_i - 2 x_i.x_j -- the minimum of the lane's 16 entries against one
+    // value (8 v_min3 + 1 compare per 1 024 pairs).  Round 3 added n_j inside the accumulator through one more MFMA (A = ones,
+    // B = n_j in three bf16 parts): a quarter of the kernel's matrix-core time, and 16 ORs for the sign test on top.
+    __shared__ float Nf[2][SCAN_CT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t qbase = (int64_t)(blockIdx.x / splits) * 128 + wave * 32;   // this wave's 32 queries (local row numbers)
@@ -410,9 +413,6 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     f32x16v negu;
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq) negu[qq] = uq[qq];
-    bf16x8k aone;                                              // A[m][k] = 1 for k = 0, 1, 2 (lanes of the first k half)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) aone[e] = (__bf16)((h == 0 && e < 3) ? 1.0f : 0.0f);
     const int64_t all_tiles = (n + SCAN_CT - 1) / SCAN_CT, per_split = (all_tiles + splits - 1) / splits;
     const int64_t tile_lo = per_split * split;
     const int64_t n_tiles = tile_lo + per_split < all_tiles ? tile_lo + per_split : all_tiles;
@@ -450,13 +450,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
             const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
             *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + off * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
         }
-        if (threadIdx.x < SCAN_CT) {
-            const unsigned b1 = __float_as_uint(nval) & 0xffff0000u;
-            const float r1 = nval - __uint_as_float(b1);                   // exact
-            const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(b2);                     // exact, at most 8 significant bits left
-            Nb[buf][threadIdx.x] = make_uint2((b1 >> 16) | b2, __float_as_uint(r2) >> 16);
-        }
+        if (threadIdx.x < SCAN_CT) Nf[buf][threadIdx.x] = -nval;
     };
     constexpr int EQ_CAP = 128;
     __shared__ unsigned long long eb[4][EQ_CAP];
@@ -476,34 +470,35 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
         qn = 0;
     };
     // Kept pairs go to a per-wave LDS queue first (the returning global atomic that reserves a list slot costs
-    // microseconds, too much inside the MFMA stream; the queue is flushed at tile ends).  The signs of a lane's 32
-    // accumulator entries (two column tiles) are packed into one word; lanes then take their set bits one per round and
-    // get queue positions from the round's ballot: no LDS atomics, a handful of branches per 2 048 pairs.
-    auto keep_pairs = [&](const f32x16v &acc0, const f32x16v &acc1, int64_t cand0) {
-        unsigned any = 0;
+    // microseconds, too much inside the MFMA stream; the queue is flushed at tile ends).  One 32 x 32 tile at a time: the lane's
+    // minimum against -n_j decides wave-wide whether anything is kept (8 v_min3 + a compare; ~70 % of the tiles end here).
+    // Otherwise the signs of acc - (-n_j) of a lane's 16 entries are packed into one word (the sign of a float32 difference is
+    // the sign of the exact difference, denormals included); lanes then take their set bits one per round and get queue
+    // positions from the round's ballot: no LDS atomics, a handful of branches per tile with something to keep.
+    const int32_t rowb = (int32_t)qbase + 4 * h;               // local row of accumulator entry q: rowb + (q & 3) + 8 (q >> 2)
+    auto keep_tile = [&](const f32x16v &acc, float negn, int32_t cand) {
+        float m = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) any |= __float_as_uint(acc0[q]) | __float_as_uint(acc1[q]);
-        if (!__ballot((any & 0x80000000u) != 0)) return;       // wave-uniform: nothing to keep in these 2 048 pairs
-        unsigned bits = 0;                                     // bit 31 - q: acc0[q] < 0, bit 15 - q: acc1[q] < 0
+        for (int q = 3; q < 15; q += 2) m = __builtin_fminf(__builtin_fminf(m, acc[q]), acc[q + 1]);
+        m = __builtin_fminf(m, acc[15]);
+        if (!__ballot(m < negn)) return;                       // wave-uniform: nothing to keep in these 1 024 pairs
+        unsigned bits = 0;                                     // bit 15 - q: acc[q] < -n
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc0[q]), 31);   // (bits << 1) | sign
-#pragma unroll
-        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc1[q]), 31);
+        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc[q] - negn), 31);   // (bits << 1) | sign
         for (;;) {
             const unsigned long long hit = __ballot(bits != 0);
             if (!hit) break;
             if (bits != 0) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
-                const int q = 15 - (b & 15);
+                const int q = 15 - b;
                 const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
-                const int64_t row = qbase + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const int32_t cand = (int32_t)(cand0 + (1 - (b >> 4)) * 32 + r);
+                const int32_t row = rowb + (q & 3) + 8 * (q >> 2);
                 if (pos < EQ_CAP) {
-                    eb[wave][pos] = ((unsigned long long)row << 32) | (unsigned)cand;
+                    eb[wave][pos] = ((unsigned long long)(unsigned)row << 32) | (unsigned)cand;
                 } else {                                       // queue full (masses of duplicates): straight to the list
                     const int32_t slot = atomicAdd(&cnt[row], 1);
-                    if (slot < FILTER_CAP) list[row * FILTER_CAP + slot] = cand;
+                    if (slot < FILTER_CAP) list[(int64_t)row * FILTER_CAP + slot] = cand;
                 }
             }
             qn += __builtin_popcountll(hit);
@@ -517,14 +512,8 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
         if (tile + 1 < n_tiles) fetch(tile + 1);
 #pragma unroll
         for (int t = 0; t < SCAN_CT / 32; t += 2) {           // two column tiles in flight: independent accumulators
-            f32x16v acc0, acc1;
-            {
-                uint2 n0 = Nb[buf][t * 32 + r], n1 = Nb[buf][(t + 1) * 32 + r];
-                if (h) { n0 = make_uint2(0u, 0u); n1 = n0; }
-                const uint4 f0 = make_uint4(n0.x, n0.y, 0u, 0u), f1 = make_uint4(n1.x, n1.y, 0u, 0u);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aone, *reinterpret_cast<const bf16x8k *>(&f0), negu, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aone, *reinterpret_cast<const bf16x8k *>(&f1), negu, 0, 0, 0);
-            }
+            f32x16v acc0 = negu, acc1 = negu;
+            const float negn0 = Nf[buf][t * 32 + r], negn1 = Nf[buf][(t + 1) * 32 + r];
             const unsigned char *b0 = &Ts[buf][(t * 32 + r) * ROWB + h * 16], *b1 = b0 + 32 * ROWB;
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
@@ -539,7 +528,9 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y0h, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y1h, acc1, 0, 0, 0);
             }
-            keep_pairs(acc0, acc1, tile * SCAN_CT + t * 32);       // a negative entry = a pair to keep
+            const int32_t cand0 = (int32_t)(tile * SCAN_CT) + t * 32 + r;     // this lane's candidate in the first column tile
+            keep_tile(acc0, negn0, cand0);                               // an entry below -n_j = a pair to keep
+            keep_tile(acc1, negn1, cand0 + 32);
         }
         if (qn >= EQ_CAP / 2) flush();
         if (tile + 1 < n_tiles) put(buf ^ 1);
