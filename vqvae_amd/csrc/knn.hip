@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
                                                            int64_t n, int64_t row0, int64_t rows, double eps, int splits,
                                                            int32_t *__restrict__ cnt, int32_t *__restrict__ list) {
     constexpr int KST = DPB / 16;                              // MFMA k-steps
-    constexpr int ROWB = 2 * DPB * 2 + 16;                     // bytes per candidate in LDS: hi, lo, 16 of padding (banks)
+    // bytes per candidate in LDS: the hi row, the lo row, no padding -- the 16-byte pieces of a row are XOR-swizzled with the row
+    // number instead, so that 16 consecutive candidates' reads of one piece spread over all banks (round 3 padded the rows to
+    // 80 bytes at d <= 16: 47 KB per workgroup, three per CU; 38 KB fit four, and the scan is bound by the waves' serial latency)
+    constexpr int ROWB = 2 * DPB * 2, PR = ROWB / 16;          // PR = 4 / 8 / 16 pieces per row
+    auto swz = [](int row) { return (row / (16 / PR)) & (PR - 1); };
     __shared__ __attribute__((aligned(16))) unsigned char Ts[2][SCAN_CT * ROWB];
     // -|x_j|^2 (1 - eps), |.| rounded down to float32: a lane's accumulator entries all belong to ONE candidate (its column), so
     // "distance below the threshold" is acc < -n_j with acc = -u_i - 2 x_i.x_j -- the minimum of the lane's 16 entries against one
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     const int r = lane & 31, h = lane >> 5;
     const int64_t qbase = (int64_t)(blockIdx.x / splits) * 128 + wave * 32;   // this wave's 32 queries (local row numbers)
     const int split = blockIdx.x % splits;                                  // ... against one slice of the corpus
+    const int sw = swz(r);                                     // swizzle of the candidate rows this lane reads (row = 32 t + r)
     // A operand: lane holds A[m = r][k = 16 ks + 8 h .. + 7] = -2 x (both parts: the scaling is exact)
     bf16x8k ahi[KST], alo[KST];
     float uq[16];                                              // u of the 16 rows this lane's accumulator entries belong to
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
         for (int k = 0; k < PER; ++k) {
             const int piece = k * 256 + threadIdx.x;
             const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
-            *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + off * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
+            *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + (off ^ swz(sc)) * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
         }
         if (threadIdx.x < SCAN_CT) Nf[buf][threadIdx.x] = -nval;
     };
@@ -510,28 +515,42 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     for (int64_t tile = tile_lo; tile < n_tiles; ++tile) {
         const int buf = (int)(tile & 1);
         if (tile + 1 < n_tiles) fetch(tile + 1);
-#pragma unroll
-        for (int t = 0; t < SCAN_CT / 32; t += 2) {           // two column tiles in flight: independent accumulators
-            f32x16v acc0 = negu, acc1 = negu;
-            const float negn0 = Nf[buf][t * 32 + r], negn1 = Nf[buf][(t + 1) * 32 + r];
-            const unsigned char *b0 = &Ts[buf][(t * 32 + r) * ROWB + h * 16], *b1 = b0 + 32 * ROWB;
+        // One 32-candidate column tile per step, software-pipelined inside the wave: the fragments of tile t + 1 are requested
+        // from LDS, the three MFMAs of tile t issued, and only then the keep test of tile t - 1 runs -- vector work and branches
+        // of one tile under the matrix-core time of the next, instead of MFMAs -> wait -> test -> branch in sequence.
+        constexpr int NT = SCAN_CT / 32;
+        bf16x8k yh[2][KST], yl[2][KST];
+        f32x16v accs[2];
+        float negns[2];
+        auto frags = [&](int t2, int slot) {
+            const unsigned char *b = &Ts[buf][(t2 * 32 + r) * ROWB];
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                const bf16x8k y0h = *reinterpret_cast<const bf16x8k *>(b0 + ks * 32);
-                const bf16x8k y0l = *reinterpret_cast<const bf16x8k *>(b0 + 2 * DPB + ks * 32);
-                const bf16x8k y1h = *reinterpret_cast<const bf16x8k *>(b1 + ks * 32);
-                const bf16x8k y1l = *reinterpret_cast<const bf16x8k *>(b1 + 2 * DPB + ks * 32);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], y1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], y1h, acc1, 0, 0, 0);
+                const int ph = ((2 * ks + h) ^ sw) * 16, pl = ((PR / 2 + 2 * ks + h) ^ sw) * 16;   // this lane's hi / lo piece
+                yh[slot][ks] = *reinterpret_cast<const bf16x8k *>(b + ph);
+                yl[slot][ks] = *reinterpret_cast<const bf16x8k *>(b + pl);
             }
-            const int32_t cand0 = (int32_t)(tile * SCAN_CT) + t * 32 + r;     // this lane's candidate in the first column tile
-            keep_tile(acc0, negn0, cand0);                               // an entry below -n_j = a pair to keep
-            keep_tile(acc1, negn1, cand0 + 32);
+            negns[slot] = Nf[buf][t2 * 32 + r];
+        };
+        const int32_t cand_t0 = (int32_t)(tile * SCAN_CT) + r;           // this lane's candidate in column tile 0
+        frags(0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cur = t & 1;
+            const float negn_prev = negns[cur ^ 1];                    // (tile t - 1's, before the slot is refilled)
+            if (t + 1 < NT) frags(t + 1, cur ^ 1);
+            f32x16v acc = negu;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], yh[cur][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], yl[cur][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], yh[cur][ks], acc, 0, 0, 0);
+            }
+            accs[cur] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0) keep_tile(accs[cur ^ 1], negn_prev, cand_t0 + (t - 1) * 32);   // an entry below -n_j = a pair to keep
         }
+        keep_tile(accs[(NT - 1) & 1], negns[(NT - 1) & 1], cand_t0 + (NT - 1) * 32);
         if (qn >= EQ_CAP / 2) flush();
         if (tile + 1 < n_tiles) put(buf ^ 1);
         __syncthreads();
@@ -558,34 +577,55 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
     const int32_t m_all = cnt[row];
     if (m_all > FILTER_CAP) { if (lane == 0) atomicAdd(overflow, 1); return; }
     const int64_t qr = row0 + row;
-    for (int32_t c0 = 0; c0 < m_all; c0 += 64) {
-        const bool valid = c0 + lane < m_all;
-        const int32_t j = valid ? list[row * FILTER_CAP + c0 + lane] : 0;
-        double acc = 0.0;
+    // U candidates per lane at a time, all of their row loads in flight before the first fma: the rows are random 64- to 256-byte
+    // gathers from a corpus far larger than the L2, and one candidate per lane and trip (round 3) paid that latency six times
+    // over per query (27 ms of the 172 ms stage at one million latents).  Per candidate the fma chain is unchanged.
+    constexpr int U = DCH <= 16 ? 4 : 2;
+    for (int32_t c0 = 0; c0 < m_all; c0 += 64 * U) {
+        int32_t j[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            valid[u] = c0 + u * 64 + lane < m_all;
+            j[u] = valid[u] ? list[row * FILTER_CAP + c0 + u * 64 + lane] : 0;
+        }
+        double acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = 0.0;
         for (int ch = 0; ch < nch; ++ch) {
-            const float4 *src = reinterpret_cast<const float4 *>(zp32 + (int64_t)j * dp + ch * DCH);
+            float4 f[U][DCH / 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 *src = reinterpret_cast<const float4 *>(zp32 + (int64_t)j[u] * dp + ch * DCH);
+#pragma unroll
+                for (int v = 0; v < DCH / 4; ++v) f[u][v] = src[v];
+            }
             const double *__restrict__ qv = zq64 + qr * dp + ch * DCH;     // wave-uniform address
 #pragma unroll
-            for (int v = 0; v < DCH / 4; ++v) {
-                const float4 f = src[v];
-                const double c4[4] = {(double)f.x, (double)f.y, (double)f.z, (double)f.w};
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (EXPANSION) {
-                        acc = fma(qv[4 * v + k], c4[k], acc);
-                    } else {
-                        const double t = qv[4 * v + k] - c4[k];
-                        acc = fma(t, t, acc);
+                for (int v = 0; v < DCH / 4; ++v) {
+                    const double c4[4] = {(double)f[u][v].x, (double)f[u][v].y, (double)f[u][v].z, (double)f[u][v].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (EXPANSION) {
+                            acc[u] = fma(qv[4 * v + k], c4[k], acc[u]);
+                        } else {
+                            const double t = qv[4 * v + k] - c4[k];
+                            acc[u] = fma(t, t, acc[u]);
+                        }
                     }
                 }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double d2 = acc[u];
+            if (EXPANSION) {
+                d2 = (nrm_q[qr] + (-2.0 * d2)) + nrm[j[u]];
+                if (!(d2 > 0.0)) d2 = 0.0;
             }
+            if (valid[u]) { sv[wave][c0 + u * 64 + lane] = d2; si[wave][c0 + u * 64 + lane] = j[u]; }
         }
-        double d2 = acc;
-        if (EXPANSION) {
-            d2 = (nrm_q[qr] + (-2.0 * d2)) + nrm[j];
-            if (!(d2 > 0.0)) d2 = 0.0;
-        }
-        if (valid) { sv[wave][c0 + lane] = d2; si[wave][c0 + lane] = j; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's own LDS writes, read back below
     __builtin_amdgcn_wave_barrier();
@@ -599,18 +639,26 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
             const int32_t id = si[wave][e];
             if (v < bv || (v == bv && id < bi)) { bv = v; bi = id; bpos = e; }
         }
+        // the wave's smallest distance first (one 8-byte value through the butterfly), then its owner: almost always one lane;
+        // equal distances in several lanes (duplicate latents) -> the lowest index among them
+        double mv = bv;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bv, off, 64);
-            const int32_t oi = __shfl_xor(bi, off, 64);
-            const int32_t op = __shfl_xor(bpos, off, 64);
-            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
+        for (int off = 32; off >= 1; off >>= 1) mv = fmin(mv, __shfl_xor(mv, off, 64));
+        if (!(mv < inf64())) break;                            // fewer candidates than kq (cannot happen: subset >= kq rows)
+        const unsigned long long tied = __ballot(bv == mv);
+        int owner = __ffsll((long long)tied) - 1;
+        if (tied & (tied - 1)) {                               // wave-uniform
+            int32_t mi = bv == mv ? bi : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
+            owner = __ffsll((long long)__ballot(bv == mv && bi == mi)) - 1;
         }
-        if (bpos < 0) break;                                   // fewer candidates than kq (cannot happen: subset >= kq rows)
-        if (lane == (bpos & 63)) sv[wave][bpos] = inf64();     // retired (real distances are finite)
+        bi = __shfl(bi, owner, 64);
+        bpos = __shfl(bpos, owner, 64);
+        if (lane == owner) sv[wave][bpos] = inf64();           // retired (real distances are finite)
         if (lane == 0) {
             idx_out[row * kq + round] = bi;
-            d2_out[row * kq + round] = bv;
+            d2_out[row * kq + round] = mv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
