@@ -569,6 +569,8 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
                                                         double *__restrict__ d2_out, int32_t *__restrict__ overflow) {
     __shared__ double sv[KNN_WAVES][FILTER_CAP];
     __shared__ int32_t si[KNN_WAVES][FILTER_CAP];
+    __shared__ double cv[KNN_WAVES][64];                       // the entries at or below the kq-th distance, compacted
+    __shared__ int32_t ci[KNN_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row = (int64_t)blockIdx.x * KNN_WAVES + wave;
@@ -629,6 +631,68 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's own LDS writes, read back below
     __builtin_amdgcn_wave_barrier();
+    // Selection.  First the value of the kq-th smallest distance by quickselect over the wave's entries: a pivot from the window
+    // (lo, hi) (lo: fewer than kq entries <= lo; hi: at least kq entries <= hi), one counting pass, ~2 ln(m) rounds of ~35
+    // instructions.  Then the entries <= that value -- kq of them unless distances tie at the threshold -- are compacted (cv / ci)
+    // and ordered by (distance, index) with a rank count, one entry per lane.  (Round 3 extracted the kq minima one by one: kq
+    // rounds of an LDS rescan + a three-value butterfly, ~1 900 instructions per query, the bulk of this kernel's time.)
+    // More than 64 entries at or below the threshold (masses of duplicates): the extraction loop below, as before.
+    if (m_all >= kq) {
+        double lo = -1.0, hi = inf64();                        // distances are >= 0 and finite
+        int rot = 0;
+        for (int guard = 0; guard < 2048; ++guard) {
+            // pivot: the first entry inside (lo, hi) of the first lane (from a rotating start) that has one
+            double cand = inf64();
+            for (int32_t e = lane; e < m_all; e += 64) {
+                const double v = sv[wave][e];
+                if (v > lo && v < hi && !(cand < inf64())) cand = v;
+            }
+            unsigned long long has = __ballot(cand < inf64());
+            if (!has) break;                                   // nothing strictly inside: the threshold is hi
+            has = (has >> rot) | (rot ? has << (64 - rot) : 0ull);
+            const int src = (__ffsll((long long)has) - 1 + rot) & 63;
+            rot = (rot + 23) & 63;
+            const double pivot = __shfl(cand, src, 64);
+            int c = 0;
+            for (int32_t e = lane; e < m_all; e += 64) c += sv[wave][e] <= pivot ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (c >= kq) hi = pivot; else lo = pivot;
+        }
+        // hi == inf: fewer than kq finite entries (cannot happen); otherwise compact the entries <= hi
+        int c_le = 0;
+        for (int32_t e = lane; e < m_all; e += 64) c_le += sv[wave][e] <= hi ? 1 : 0;
+        int incl = c_le;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (hi < inf64() && total <= 64) {
+            int at = incl - c_le;
+            for (int32_t e = lane; e < m_all; e += 64) {
+                const double v = sv[wave][e];
+                if (v <= hi) { cv[wave][at] = v; ci[wave][at] = si[wave][e]; ++at; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // rank of this lane's entry among the `total` compacted ones in (distance, index) order
+            const double myv = lane < total ? cv[wave][lane] : inf64();
+            const int32_t myi = lane < total ? ci[wave][lane] : 0x7fffffff;
+            int rank = 0;
+            for (int t2 = 0; t2 < total; ++t2) {
+                const double ov = cv[wave][t2];
+                const int32_t oi = ci[wave][t2];
+                rank += (ov < myv || (ov == myv && oi < myi)) ? 1 : 0;
+            }
+            if (lane < total && rank < kq) {
+                idx_out[row * kq + rank] = myi;
+                d2_out[row * kq + rank] = myv;
+            }
+            return;
+        }
+    }
     // kq rounds of "extract the minimum in (distance, index) order": every lane scans its own strided entries,
     // a butterfly finds the wave's minimum, its owner retires it
     for (int round = 0; round < kq; ++round) {
