@@ -221,6 +221,31 @@ def test_large_corpus_with_masses_of_duplicates_falls_back():
     assert (d2[5000:8000] == 0).all() and (idx[5000:8000, 0] == 5000).all()     # lowest indices among the copies first
 
 
+@pytest.mark.parametrize("copies", [30, 100])
+def test_filter_path_with_ties_at_the_kq_th_distance(copies):
+    """Groups of identical latents small enough for the candidate lists (cap 1 024) but tying at the kq-th distance: the
+    refinement's selection (quickselect for the kq-th distance, then the entries at or below it ordered by (distance, index))
+    must cut the tie by index like the oracle -- 30 copies: more entries at the threshold than kq, one per lane; 100 copies:
+    more than the 64 lanes hold, the one-by-one extraction takes over."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    n, d, kq = 42000, 16, 21
+    z = latents(n, d, 29)
+    for g in range(20):                                         # 20 groups of `copies` identical rows, scattered
+        rows = 1000 + 2000 * g + 7 * np.arange(copies)
+        z[rows] = z[rows[0]]
+    idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for r0, r1 in ((990, 1022), (1000 + 7 * (copies - 1) - 8, 1000 + 7 * (copies - 1) + 8), (39000, 39032), (n - 32, n)):
+        io, do = _oracle_rows(z, kq, 1, r0, r1)
+        np.testing.assert_array_equal(d2[r0:r1], do)
+        np.testing.assert_array_equal(idx[r0:r1], io)
+    first = 1000 + 7 * np.arange(kq)
+    np.testing.assert_array_equal(idx[1000 + 7 * (copies - 1)], first)          # the last copy: the kq lowest-indexed copies
+    assert (d2[1000 + 7 * (copies - 1)] == 0).all()
+
+
 def test_lcc_and_connectivity(golden):
     from vqvae_amd.geo.knn_graph_optimized import (analyze_graph_connectivity, build_knn_graph,
                                                    largest_connected_component)
