@@ -352,24 +352,36 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
 }
 
 // zb [n][2][dpb] bf16 bit patterns: the two parts of every coordinate (dpb = dp rounded up to 16, zero padded)
-__global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ zp32, int64_t n, int dp, int dpb,
-                                                       unsigned short *__restrict__ zb) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * dpb; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ zp32, const double *__restrict__ nrm,
+                                                       int64_t n, int64_t n_pad, int dp, int dpb, double eps,
+                                                       unsigned short *__restrict__ zb, float *__restrict__ negn) {
+    // rows n .. n_pad - 1 (the scan reads whole tiles of 256 candidates): zeros, and a threshold nothing falls below
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad * dpb; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / dpb;
         const int c = (int)(i % dpb);
-        const float x = c < dp ? zp32[r * dp + c] : 0.0f;
+        const float x = (c < dp && r < n) ? zp32[r * dp + c] : 0.0f;
         const unsigned short hi = bf16_rne(x);
         const float rest = x - __uint_as_float((unsigned)hi << 16);      // exact
         zb[(r * 2 + 0) * dpb + c] = hi;
         zb[(r * 2 + 1) * dpb + c] = bf16_rne(rest);
+        if (c == 0) {
+            // -|x_j|^2 (1 - eps), the magnitude rounded DOWN to float32 (the scan keeps a pair when acc < this)
+            float nval = 3.0e38f;
+            if (r < n) {
+                const double nd = nrm[r] * (1.0 - eps);
+                nval = (float)nd;
+                if ((double)nval > nd) nval = nextafterf(nval, -3.4e38f);
+            }
+            negn[r] = -nval;
+        }
     }
 }
 
 template <int DPB, int SCAN_CT>
 __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short *__restrict__ zb,
                                                            const unsigned short *__restrict__ zbq,
-                                                           const double *__restrict__ nrm, const double *__restrict__ u,
-                                                           int64_t n, int64_t row0, int64_t rows, double eps, int splits,
+                                                           const float *__restrict__ negn, const double *__restrict__ u,
+                                                           int64_t n, int64_t row0, int64_t rows, int splits,
                                                            int32_t *__restrict__ cnt, int32_t *__restrict__ list) {
     constexpr int KST = DPB / 16;                              // MFMA k-steps
     // bytes per candidate in LDS: the hi row, the lo row, no padding -- the 16-byte pieces of a row are XOR-swizzled with the row
@@ -422,40 +434,30 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     const int64_t tile_lo = per_split * split;
     const int64_t n_tiles = tile_lo + per_split < all_tiles ? tile_lo + per_split : all_tiles;
     if (tile_lo >= n_tiles) return;
-    // staging: a candidate's 4 DPB bytes (hi row, lo row) are contiguous in zb; PER 16-byte pieces per thread
-    constexpr int PIECES = SCAN_CT * (4 * DPB / 16);           // 16-byte pieces per tile
+    // staging: a tile's candidates are one contiguous run of SCAN_CT x 4 DPB bytes in zb (rows padded to whole tiles by
+    // knn_split_kernel, so no index is clamped): piece k * 256 + tid of 16 bytes per thread and k, from a wave-uniform base
+    constexpr int PIECES = SCAN_CT * PR;                       // 16-byte pieces per tile
     constexpr int PER = PIECES / 256;
     static_assert(PIECES % 256 == 0, "tile pieces divide among the threads");
-    unsigned vals[PER][4];
-    float nval = 3.0e38f;
+    unsigned vals[PER][4];                                     // (scalars: an array of uint4 stays in scratch memory)
+    float nval = 0.f;
     auto fetch = [&](int64_t tile) {
-        const int64_t c0 = tile * SCAN_CT;
+        const uint4 *tp = reinterpret_cast<const uint4 *>(zb + tile * SCAN_CT * 2 * DPB);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int piece = k * 256 + threadIdx.x;
-            const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
-            const int64_t j = c0 + sc < n ? c0 + sc : n - 1;
-            const uint4 f = *reinterpret_cast<const uint4 *>(zb + j * 2 * DPB + off * 8);
+            const uint4 f = tp[k * 256 + threadIdx.x];
             vals[k][0] = f.x; vals[k][1] = f.y; vals[k][2] = f.z; vals[k][3] = f.w;
         }
-        if (threadIdx.x < SCAN_CT) {
-            const int64_t jj = c0 + threadIdx.x;
-            nval = 3.0e38f;                                    // beyond the corpus: never kept
-            if (jj < n) {
-                const double nd = nrm[jj] * (1.0 - eps);
-                nval = (float)nd;
-                if ((double)nval > nd) nval = nextafterf(nval, -3.4e38f);
-            }
-        }
+        if (threadIdx.x < SCAN_CT) nval = negn[tile * SCAN_CT + threadIdx.x];
     };
     auto put = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int piece = k * 256 + threadIdx.x;
-            const int sc = piece / (4 * DPB / 16), off = piece % (4 * DPB / 16);
+            const int sc = piece / PR, off = piece % PR;
             *reinterpret_cast<uint4 *>(&Ts[buf][sc * ROWB + (off ^ swz(sc)) * 16]) = make_uint4(vals[k][0], vals[k][1], vals[k][2], vals[k][3]);
         }
-        if (threadIdx.x < SCAN_CT) Nf[buf][threadIdx.x] = -nval;
+        if (threadIdx.x < SCAN_CT) Nf[buf][threadIdx.x] = nval;
     };
     constexpr int EQ_CAP = 128;
     __shared__ unsigned long long eb[4][EQ_CAP];
@@ -482,14 +484,29 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
     // positions from the round's ballot: no LDS atomics, a handful of branches per tile with something to keep.
     const int32_t rowb = (int32_t)qbase + 4 * h;               // local row of accumulator entry q: rowb + (q & 3) + 8 (q >> 2)
     auto keep_tile = [&](const f32x16v &acc, float negn, int32_t cand) {
-        float m = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
-#pragma unroll
-        for (int q = 3; q < 15; q += 2) m = __builtin_fminf(__builtin_fminf(m, acc[q]), acc[q + 1]);
-        m = __builtin_fminf(m, acc[15]);
-        if (!__ballot(m < negn)) return;                       // wave-uniform: nothing to keep in these 1 024 pairs
+        // (the two halves of the lane's entries separately: a tile that keeps something builds the sign word of one half only)
+        float ma = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
+        float mb = __builtin_fminf(__builtin_fminf(acc[8], acc[9]), acc[10]);
+        ma = __builtin_fminf(__builtin_fminf(ma, acc[3]), acc[4]);
+        mb = __builtin_fminf(__builtin_fminf(mb, acc[11]), acc[12]);
+        ma = __builtin_fminf(__builtin_fminf(ma, acc[5]), acc[6]);
+        mb = __builtin_fminf(__builtin_fminf(mb, acc[13]), acc[14]);
+        ma = __builtin_fminf(ma, acc[7]);
+        mb = __builtin_fminf(mb, acc[15]);
+        if (!__ballot(__builtin_fminf(ma, mb) < negn)) return;  // wave-uniform: nothing to keep in these 1 024 pairs
         unsigned bits = 0;                                     // bit 15 - q: acc[q] < -n
+        if (__ballot(ma < negn)) {
+            unsigned w = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc[q] - negn), 31);   // (bits << 1) | sign
+            for (int q = 0; q < 8; ++q) w = __builtin_amdgcn_alignbit(w, __float_as_uint(acc[q] - negn), 31);   // (w << 1) | sign
+            bits = w << 8;
+        }
+        if (__ballot(mb < negn)) {
+            unsigned w = 0;
+#pragma unroll
+            for (int q = 8; q < 16; ++q) w = __builtin_amdgcn_alignbit(w, __float_as_uint(acc[q] - negn), 31);
+            bits |= w;
+        }
         for (;;) {
             const unsigned long long hit = __ballot(bits != 0);
             if (!hit) break;
@@ -779,12 +796,13 @@ extern "C" size_t geo_knn_workspace_bytes(int64_t n, int32_t d) {
     if (filter_applies(n, p.dp)) {
         const size_t m = ((size_t)n + FILTER_STRIDE - 1) / FILTER_STRIDE;
         const size_t dpb = p.dp < 16 ? 16 : p.dp;
+        const size_t n_pad = ((size_t)n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256;   // the scan reads whole tiles
         b += geo::align_up(m * p.dp * sizeof(float)) + geo::align_up(m * sizeof(double)) + geo::align_up((size_t)n * 8) +
              geo::align_up((size_t)n * 4) + geo::align_up((size_t)n * FILTER_CAP * 4) + 256 +
-             geo::align_up((size_t)n * 2 * dpb * sizeof(unsigned short));
+             geo::align_up(n_pad * 2 * dpb * sizeof(unsigned short)) + geo::align_up(n_pad * sizeof(float));
         const size_t m0 = (m + FILTER_STRIDE - 1) / FILTER_STRIDE;
         b += geo::align_up(m0 * p.dp * sizeof(float)) + geo::align_up(m0 * sizeof(double)) +
-             geo::align_up(m * 2 * dpb * sizeof(unsigned short));                           // two-level thresholds
+             geo::align_up(m_pad * 2 * dpb * sizeof(unsigned short)) + geo::align_up(m_pad * sizeof(float));   // two-level thresholds
     }
     return b;
 }
@@ -828,13 +846,16 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         int32_t *overflow = ar.take<int32_t>(16);
         const int dpb = p.dp < 16 ? 16 : p.dp;
         const bool bf16_scan = geo::options().knn_filter != 2;         // 2: the float32 matrix-core scan (comparison runs)
-        unsigned short *zb = ar.take<unsigned short>((size_t)n * 2 * dpb);
+        const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256;      // the scan reads whole tiles
+        unsigned short *zb = ar.take<unsigned short>((size_t)n_pad * 2 * dpb);
+        float *negn = ar.take<float>((size_t)n_pad);
         const size_t m0w = ((size_t)m + FILTER_STRIDE - 1) / FILTER_STRIDE;
         float *zs0 = ar.take<float>(m0w * p.dp);
         double *nrm_s0 = ar.take<double>(m0w);
-        unsigned short *zb_s = ar.take<unsigned short>((size_t)m * 2 * dpb);
-        if (!zs0 || !nrm_s0 || !zb_s) zs0 = nullptr;          // (a caller with the older, smaller workspace: one level)
-        if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow || !zb) {
+        unsigned short *zb_s = ar.take<unsigned short>((size_t)m_pad * 2 * dpb);
+        float *negn_s = ar.take<float>((size_t)m_pad);
+        if (!zs0 || !nrm_s0 || !zb_s || !negn_s) zs0 = nullptr;   // (a caller with a smaller workspace: one level)
+        if (!zs32 || !nrm_s || !u || !cnt || !list || !overflow || !zb || !negn) {
             geo::set_error("geo_knn_topk: workspace %zu too small", ws_bytes);
             return GEO_E_WORKSPACE;
         }
@@ -846,7 +867,7 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         knn_subset_kernel<<<geo::grid_for(m * p.dp, 256, 4096), 256, 0, stream>>>(zp32, nrm, n, p.dp, FILTER_STRIDE, m, zs32, nrm_s);
         GEO_LAUNCH_CHECK();
         if (bf16_scan) {
-            knn_split_kernel<<<geo::grid_for((int64_t)n * dpb, 256, 4096), 256, 0, stream>>>(zp32, n, p.dp, dpb, zb);
+            knn_split_kernel<<<geo::grid_for(n_pad * dpb, 256, 4096), 256, 0, stream>>>(zp32, nrm, n, n_pad, p.dp, dpb, eps, zb, negn);
             GEO_LAUNCH_CHECK();
         }
         const unsigned rgrid = (unsigned)((rows + KNN_WAVES - 1) / KNN_WAVES);
@@ -883,13 +904,13 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
             if (rc) return rc;
             knn_tau_kernel<<<geo::grid_for(rows, 256, 4096), 256, 0, stream>>>(d2_out, nrm, row0, rows, n_neighbors, eps, u, cnt);
             GEO_LAUNCH_CHECK();
-            knn_split_kernel<<<geo::grid_for((int64_t)m * dpb, 256, 4096), 256, 0, stream>>>(zs32, m, p.dp, dpb, zb_s);
+            knn_split_kernel<<<geo::grid_for(m_pad * dpb, 256, 4096), 256, 0, stream>>>(zs32, nrm_s, m, m_pad, p.dp, dpb, eps, zb_s, negn_s);
             GEO_LAUNCH_CHECK();
             const int sp1 = splits_for(m);
             const unsigned g1 = (unsigned)((rows + 127) / 128) * (unsigned)sp1;
-            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
-            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
-            else knn_scan_bf16_kernel<64, 128><<<g1, 256, 0, stream>>>(zb_s, zb, nrm_s, u, m, row0, rows, eps, sp1, cnt, list);
+            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<g1, 256, 0, stream>>>(zb_s, zb, negn_s, u, m, row0, rows, sp1, cnt, list);
+            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<g1, 256, 0, stream>>>(zb_s, zb, negn_s, u, m, row0, rows, sp1, cnt, list);
+            else knn_scan_bf16_kernel<64, 128><<<g1, 256, 0, stream>>>(zb_s, zb, negn_s, u, m, row0, rows, sp1, cnt, list);
             GEO_LAUNCH_CHECK();
             GEO_REFINE_ANY(zs32, nrm_s);                       // kq smallest exact distances to the subset -> d2_out
             GEO_LAUNCH_CHECK();
@@ -908,9 +929,9 @@ extern "C" int geo_knn_topk(const float *z, int64_t n, int32_t d, int32_t n_neig
         const int splits = splits_for(n);
         const unsigned sgrid = (unsigned)((rows + 127) / 128) * (unsigned)splits;
         if (bf16_scan) {
-            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
-            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
-            else knn_scan_bf16_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zb, zb, nrm, u, n, row0, rows, eps, splits, cnt, list);
+            if (dpb == 16) knn_scan_bf16_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zb, zb, negn, u, n, row0, rows, splits, cnt, list);
+            else if (dpb == 32) knn_scan_bf16_kernel<32, 256><<<sgrid, 256, 0, stream>>>(zb, zb, negn, u, n, row0, rows, splits, cnt, list);
+            else knn_scan_bf16_kernel<64, 128><<<sgrid, 256, 0, stream>>>(zb, zb, negn, u, n, row0, rows, splits, cnt, list);
         } else
         if (p.dp == 8) knn_scan_kernel<8, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
         else if (p.dp == 16) knn_scan_kernel<16, 256><<<sgrid, 256, 0, stream>>>(zp32, nrm, u, n, row0, rows, eps, splits, cnt, list);
