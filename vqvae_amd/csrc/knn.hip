@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
                                                         const int32_t *__restrict__ list, int32_t *__restrict__ idx_out,
                                                         double *__restrict__ d2_out, int32_t *__restrict__ overflow) {
     __shared__ double sv[KNN_WAVES][FILTER_CAP];
-    __shared__ int32_t si[KNN_WAVES][FILTER_CAP];
+    // (the index of entry e is list[row][e]: no copy of it in LDS -- 35 KB per workgroup instead of 51, four per CU)
     __shared__ double cv[KNN_WAVES][64];                       // the entries at or below the kq-th distance, compacted
     __shared__ int32_t ci[KNN_WAVES][64];
     const int lane = threadIdx.x & 63;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
                 d2 = (nrm_q[qr] + (-2.0 * d2)) + nrm[j[u]];
                 if (!(d2 > 0.0)) d2 = 0.0;
             }
-            if (valid[u]) { sv[wave][c0 + u * 64 + lane] = d2; si[wave][c0 + u * 64 + lane] = j[u]; }
+            if (valid[u]) sv[wave][c0 + u * 64 + lane] = d2;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's own LDS writes, read back below
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
             int at = incl - c_le;
             for (int32_t e = lane; e < m_all; e += 64) {
                 const double v = sv[wave][e];
-                if (v <= hi) { cv[wave][at] = v; ci[wave][at] = si[wave][e]; ++at; }
+                if (v <= hi) { cv[wave][at] = v; ci[wave][at] = list[row * FILTER_CAP + e]; ++at; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const float *__restrict
         int32_t bi = 0x7fffffff, bpos = -1;
         for (int32_t e = lane; e < m_all; e += 64) {
             const double v = sv[wave][e];
-            const int32_t id = si[wave][e];
+            const int32_t id = list[row * FILTER_CAP + e];
             if (v < bv || (v == bv && id < bi)) { bv = v; bi = id; bpos = e; }
         }
         // the wave's smallest distance first (one 8-byte value through the butterfly), then its owner: almost always one lane;
