@@ -126,6 +126,54 @@ def test_kpp_draw_matches_oracle_draw():
     assert _next_center(np.random.RandomState(1), 3, np.zeros(3, np.float32), [0]) in (1, 2)
 
 
+def test_host_draw_with_given_deviate_equals_randomstate_choice():
+    """The draw the host makes when the device declines one (`_draw_with_u`: no copy for finite distances, float64 cumulative sum
+    taken directly, the division by cdf[-1] only around the answer) is RandomState.choice(N, p=probs) with that deviate -- also
+    for deviates sitting exactly on, just below and just above a step of the cdf, with inf / zero distances, N = 1."""
+    from vqvae_amd.geo.kmeans_optimized import _draw_with_u
+
+    def choice_with_u(N, d_min, centers, u):                    # kmeans_optimized.py:47-61 + numpy's legacy choice, spelled out
+        finite = np.isfinite(d_min)
+        safe = np.where(finite, d_min, np.max(d_min[finite]) * 2.0) if finite.any() else np.ones_like(d_min)
+        probs = safe ** 2
+        probs[centers] = 0.0
+        total = probs.sum()
+        if not total > 0:
+            return None
+        probs /= total
+        cdf = probs.astype(np.float64).cumsum()
+        cdf /= cdf[-1]
+        return int(cdf.searchsorted(u, side="right"))
+
+    r = np.random.RandomState(0)
+    for trial in range(120):
+        N = int(r.choice([1, 2, 5, 100, 1000, 8193, 50000]))
+        d = np.abs(r.randn(N)).astype(np.float32)
+        kind = trial % 5
+        if kind == 1:
+            d[r.rand(N) < 0.3] = np.inf
+        elif kind == 2:
+            d[:] = np.inf
+        elif kind == 3:
+            d[r.rand(N) < 0.7] = 0
+        elif kind == 4:
+            d[:] = 0
+        centers = list(r.choice(N, size=min(N, int(r.randint(1, 5))), replace=False))
+        deviates = [float(r.rand()), 0.0, 1.0 - 1e-16]
+        if choice_with_u(N, d.copy(), centers, 0.5) is not None:
+            f = np.isfinite(d)
+            safe = np.where(f, d, np.max(d[f]) * 2.0) if f.any() else np.ones_like(d)
+            p = safe ** 2
+            p[centers] = 0
+            p /= p.sum()
+            cdf = p.astype(np.float64).cumsum()
+            cdf /= cdf[-1]
+            for j in r.randint(0, N, 4):
+                deviates += [u for u in (float(cdf[j]), float(np.nextafter(cdf[j], 0)), float(np.nextafter(cdf[j], 2))) if u < 1]
+        for u in deviates:
+            assert _draw_with_u(N, d.copy(), centers, u) == choice_with_u(N, d.copy(), centers, u), (N, kind, u)
+
+
 def test_decoder_module_and_export_on_cpu():
     from oracle import metric as om
     from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder, looks_like_spatial_decoder, make_norm
