@@ -403,8 +403,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("GEO_BENCH_PIPELINE", "4")),
-                    help="independent builds in flight on one GPU, each on its own HIP stream and host thread (1 = one after the other)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("GEO_BENCH_PIPELINE", "0")),
+                    help="independent builds in flight on one GPU, each on its own HIP stream and host thread (1 = one after the other; "
+                         "0 = as many as fit: every build in flight owns its workspaces -- ~25 GB at the c2 size -- so the number is "
+                         "taken from the memory one warmed-up build reserved, at most 8 on one GPU and 4 per rank of a multi-GPU run)")
     ap.add_argument("--replicas", action="store_true", default=os.environ.get("GEO_BENCH_REPLICAS", "0") == "1",
                     help="N > 1: every GPU builds its own codebooks (weak scaling, no data-path collective) instead of sharding each build")
     args = ap.parse_args()
@@ -457,25 +459,30 @@ def main():
         return
     z, dec, cfg = make_inputs(args.workload, dev)
     # Builds are independent of each other, and 40 % of one build is the k-means++ chain on ONE compute unit: with
-    # --pipeline P (default 4) P builds are in flight, each driven by its own host thread on its own HIP stream with its own
-    # workspace and decoder copy, so one build's chain runs beside the next build's kNN / JVP on the other 255 CUs.  Every
+    # --pipeline P (default: as many as fit in 80 % of the free HBM, at most 8; 8 at the c2 size) P builds are in flight, each driven
+    # by its own host thread on its own HIP stream with its own workspace and decoder copy, so one build's chain runs beside the
+    # next builds' kNN / JVP on the other CUs (measured on one box, c2: 31.5 ms per build at depth 4 and 5, 29.1-29.6 at 8, 29.5 at 10).  Every
     # step still does all of its work and is checked; `ms_per_step` is elapsed / steps (throughput), the latency of a single
     # build is reported beside it.  Ranks of a multi-GPU run issue collectives in program order: no pipelining there.
     import copy
     import threading
     replicas = world > 1 and args.replicas          # every rank on its own: builds are independent objects
     shard_world = 1 if replicas else world          # ranks ONE build is sharded over
-    depth = max(1, args.pipeline)               # builds in flight per rank (sharded builds: collectives issued in ticket order)
+    auto_depth = args.pipeline <= 0
+    depth = max(1, args.pipeline)               # builds in flight per rank (sharded builds: collectives issued in ticket order); auto: set below
     solo = None
     if replicas:                                    # a process group of this rank alone: the sharding helpers then see world 1
         import torch.distributed as dist
         solo = [dist.new_group([r]) for r in range(world)][rank]
-    slots = [(torch.cuda.Stream(device=dev), copy.deepcopy(dec)) for _ in range(depth)] if depth > 1 else [(torch.cuda.current_stream(dev), dec)]
+    if auto_depth or depth > 1:
+        slots = [(torch.cuda.Stream(device=dev), copy.deepcopy(dec))]           # the others follow once the depth is known
+    else:
+        slots = [(torch.cuda.current_stream(dev), dec)]
     timers, prof, res = {}, (0.0, 0), None
     all_same = []
 
     from vqvae_amd.pipeline import run_pipelined
-    streams = [st for st, _ in slots]
+    streams = []                                     # (filled once every slot exists)
 
     from vqvae_amd.parallel import CollectiveOrder, OrderedGroup
     order = [None]                                   # sharded builds in flight: one ticket order per timed region
@@ -523,12 +530,37 @@ def main():
 
     fallback_note = None
     region_prof = []
+    depth_rule = "given on the command line"
     with contextlib.redirect_stdout(sys.stderr):
-        for sl in range(depth):                                   # every slot warms up its own stream and workspace
+        sl = -1
+        while True:                                               # every slot warms up its own stream and workspace
+            sl += 1
+            if sl >= len(slots):
+                if sl >= depth:
+                    break
+                slots.append((torch.cuda.Stream(device=dev), copy.deepcopy(dec)))
+            reserved0 = torch.cuda.memory_reserved(dev)
             with torch.cuda.stream(slots[sl][0]):
-                for _ in range(args.warmup):
+                for _ in range(max(1, args.warmup) if (auto_depth and sl == 0) else args.warmup):
                     hot_path_step(z, slots[sl][1], cfg, None, rank if not replicas else 0, shard_world, solo)
+            if auto_depth and sl == 0:
+                # one build's workspaces are reserved now: as many builds in flight as fit in 80 % of what is free, counting one
+                # more set for the instrumented build after the timed region; at most 8 (4 per rank when builds are sharded)
+                torch.cuda.synchronize(dev)
+                per_slot = max(1, torch.cuda.memory_reserved(dev) - reserved0)
+                free_now = torch.cuda.mem_get_info(dev)[0]
+                cap = 8 if shard_world == 1 else 4
+                depth = int(min(cap, max(1, 1 + (0.8 * free_now - per_slot) // per_slot)))
+                if world > 1:                                     # every rank must run the same number of builds in flight
+                    import torch.distributed as dist
+                    t = torch.tensor([depth], dtype=torch.int64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    depth = int(t.item())
+                depth_rule = (f"auto: one warmed-up build reserved {per_slot / 2**30:.1f} GiB, {free_now / 2**30:.1f} GiB were free "
+                              f"-> {depth} in flight (80 % of the free memory, one set kept for the instrumented build, cap {cap})")
+        streams[:] = [st for st, _ in slots]
         guarded = shard_world > 1 and depth > 1
+        depth_tried = depth
         if guarded:
             # Sharded builds in flight need every rank to issue its collectives in one order (parallel.CollectiveOrder).  That
             # order is by construction, but this repository's own runs never had more than one GPU: a region with one build
@@ -635,7 +667,7 @@ def main():
         "config": {"workload": f"{args.workload}: N={cfg['n']} latents d={cfg['d']} k={cfg['k']} K={cfg['K']} "
                                f"{cfg['size']}px decoder BN-train batch 512 sym=union init=kpp seed=42",
                    "graph": {"nodes": n, "nnz": nnz, "edges_reweighted": res["n_edges"]},
-                   "parallelism": parallelism, "pipeline_depth": depth,
+                   "parallelism": parallelism, "pipeline_depth": depth, "pipeline_depth_rule": depth_rule,
                    "pipeline": (f"{depth} independent builds in flight, one host thread + HIP stream + workspace each" if depth > 1
                                 else "one build after the other")},
         "latency_ms_single_build": latency_ms,
@@ -661,7 +693,7 @@ def main():
     }
     if guarded:
         out["config"]["regions_timed"] = {"one_build_after_the_other_ms_per_build": elapsed_plain / args.steps * 1e3,
-                                          "builds_in_flight_tried": args.pipeline, "reported": "in flight" if depth > 1 else "one after the other",
+                                          "builds_in_flight_tried": depth_tried, "reported": "in flight" if depth > 1 else "one after the other",
                                           "note": fallback_note}
     # compute-bound stages: kNN as 2*N^2*d flop vs the fp64 vector peak, JVP as 3.47 MFLOP/edge vs the
     # f32-MFMA peak; stage wall time (whole stage incl. graph assembly / BN statistics), this rank's share of the work

@@ -124,8 +124,17 @@ def test_bench_two_ranks_with_sharded_builds_in_flight():
         assert len(js) == 1, out.stdout[-2000:]
         lines[gpus] = json.loads(js[0])
     one, two = lines[1], lines[2]
-    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["pipeline_depth"] == 3
-    assert "ticket order" in two["config"]["parallelism"] and "kNN query rows" in two["config"]["parallelism"]
+    # the line reports the faster of its two timed regions (one build after the other / three in flight): which one wins on two
+    # ranks sharing one card is a matter of timing, what was tried and what is reported must be said either way
+    tried = two["config"]["regions_timed"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and tried["builds_in_flight_tried"] == 3
+    assert two["config"]["pipeline_depth"] in (1, 3)
+    assert tried["reported"] == ("in flight" if two["config"]["pipeline_depth"] == 3 else "one after the other")
+    if two["config"]["pipeline_depth"] == 3:
+        assert "ticket order" in two["config"]["parallelism"]
+    else:
+        assert "not faster" in tried["note"]                      # (it ran to the end and agreed: the QE check below covers both regions)
+    assert "kNN query rows" in two["config"]["parallelism"]
     assert two["parity_selfcheck"]["batched_assign_equals_fused"] is True
     assert two["parity_selfcheck"]["qe"] == one["parity_selfcheck"]["qe"]
     assert two["config"]["graph"] == one["config"]["graph"]
