@@ -405,7 +405,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("GEO_BENCH_PIPELINE", "0")),
                     help="independent builds in flight on one GPU, each on its own HIP stream and host thread (1 = one after the other; "
-                         "0 = as many as fit: every build in flight owns its workspaces -- ~25 GB at the c2 size -- so the number is "
+                         "0 = as many as fit: every build in flight owns its workspaces -- ~14 GB at the c2 size -- so the number is "
                          "taken from the memory one warmed-up build reserved, at most 8 on one GPU and 4 per rank of a multi-GPU run)")
     ap.add_argument("--replicas", action="store_true", default=os.environ.get("GEO_BENCH_REPLICAS", "0") == "1",
                     help="N > 1: every GPU builds its own codebooks (weak scaling, no data-path collective) instead of sharding each build")

@@ -1660,7 +1660,7 @@ struct Plan {
     size_t bytes;
 };
 
-constexpr int64_t MAX_SLOTS_PER_PASS = 1 << 21;      // bounds the activation workspace (~25 GB at the shipped sizes)
+constexpr int64_t MAX_SLOTS_PER_PASS = 1 << 20;      // bounds the activation workspace (~12.5 GB; the C2 graph takes two passes)
 
 // bytes of the per-node primal buffers (pre2 of every latent + the sigmoid of every output), 0 when the decoder / sizes do not
 // take that path
