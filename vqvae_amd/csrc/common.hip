@@ -29,6 +29,7 @@ const OptionName kOptionNames[] = {
     {"jvp_front_valu", "GEO_JVP_FRONT_VALU", &Options::jvp_front_valu},
     {"jvp_per_node", "GEO_JVP_PER_NODE", &Options::jvp_per_node},
     {"jvp_node_jacobian", "GEO_JVP_NODE_JACOBIAN", &Options::jvp_node_jacobian},
+    {"jvp_pipe_grid", "GEO_JVP_PIPE_GRID", &Options::jvp_pipe_grid},
 };
 Options from_environment() {
     Options o;

@@ -38,6 +38,7 @@ struct Options {
         sssp_trace = 0, sssp_u32 = 1, sssp_push = 1 /* near-far push solve for long geodesics; 2 = for every graph */,
         sssp_delta = 8 /* near-far bucket width in mean edge weights */, sssp_order = 0 /* sources ordered along 0: two exact landmark distances, 1: graph cells, 2: two landmark hop counts (1, 2: cheaper to compute, worse batches on the bench's swiss graph) */, sssp_push_blocks = 64, knn_filter = 1, kpp_grid = 256, kpp_profile = 0, jvp_mid = 0 /* 1 = f32 MFMA, 2 = per-chunk bf16 x 3 */,
         jvp_back_valu = 0, jvp_front_valu = 0, jvp_per_node = 1 /* fixed-statistics decoders: primal ConvT2 / ConvT3 once per latent */,
+        jvp_pipe_grid = 1 /* workgroups of the persistent ConvT2 kernel per CU-count (its tiles are dealt round-robin; more, shorter workgroups fill in behind other builds' resident kernels) */,
         jvp_node_jacobian = 1 /* fixed statistics, d <= 16: decoder Jacobian once per latent, edge ends from its columns (1: when the graph has enough edges per latent, 2: always, 0: never) */;
 };
 Options &options();

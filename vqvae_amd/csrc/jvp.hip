@@ -1937,7 +1937,8 @@ int run_jvp(const geo_decoder_desc *dc, const float *z, int64_t n_nodes, const i
                 GEO_HIP_CHECK(hipGetDeviceProperties(&prop, devid));
                 n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             }
-            const unsigned pgrid = (unsigned)std::min<int64_t>(p_tiles, n_cu);      // one persistent workgroup per CU
+            const int per_cu = geo::options().jvp_pipe_grid > 0 ? geo::options().jvp_pipe_grid : 1;
+            const unsigned pgrid = (unsigned)std::min<int64_t>(p_tiles, (int64_t)n_cu * per_cu);   // persistent workgroups, one resident per CU
             mid_pipe_kernel<<<pgrid, 512, 0, stream>>>(pre1, tpre1, k1, batch_stats ? 1 : 0, pl.tiles_per_group, (int)p_tiles,
                                                        s.c2, B3, dc->b2, pre2, tpre2, part2, batch_stats ? 1 : 0, e_base,
                                                        n_edges, batch);
