@@ -1,3 +1,4 @@
+"""bench.py with a report of the GPU memory it reserved (stderr, at exit): usage as bench.py, e.g. mem_probe_bench.py --pipeline 8 --no-cpu-baseline"""
 import runpy, sys, torch, atexit
 def report():
     try:
