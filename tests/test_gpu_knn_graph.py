@@ -166,6 +166,24 @@ def test_large_corpus_filter_path_vs_oracle(d, filt):
     assert (idx[:, 0] == np.arange(n)).all() and (np.diff(d2, axis=1) >= 0).all()
 
 
+@pytest.mark.parametrize("n", [40960, 40961, 41215])
+def test_filter_path_at_tile_boundaries_vs_oracle(n):
+    """The scan reads the corpus in whole tiles of 256 candidates from a zero-padded copy whose padding rows carry a threshold
+    nothing falls below: a corpus that is an exact multiple of the tile, one row more, one row less than the next multiple."""
+    import torch
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.knn_graph_optimized import knn_search_device
+    kq = 21
+    z = latents(n, 16, 31)
+    idx, d2 = knn_search_device(torch.from_numpy(z).to(device()), kq)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for r0, r1 in ((0, 32), (n - 300, n - 268), (n - 32, n)):
+        io, do = _oracle_rows(z, kq, 1, r0, r1)
+        np.testing.assert_array_equal(idx[r0:r1], io)
+        np.testing.assert_array_equal(d2[r0:r1], do)
+    assert (idx[:, 0] == np.arange(n)).all() and (idx >= 0).all() and (idx < n).all()
+
+
 @pytest.mark.parametrize("filt", [1, 2])
 def test_filter_margins_hold_far_from_the_origin(filt):
     """Latents shifted by +40 in every coordinate: norms (25 600) dwarf the neighbour distances (~10), so the filter's
