@@ -321,6 +321,38 @@ def test_per_latent_jacobian_route_matches_the_per_edge_end_path(norm, training,
 
 
 @pytest.mark.gpu
+def test_per_latent_jacobian_route_over_several_passes(request):
+    """70 001 latents x 16 unit tangents = 1.12 M tangent slots: more than one pass of the activation workspace (2^20 slots), the
+    columns of a latent pair may straddle two passes.  Against the per-edge-end path on 600 000 edges."""
+    from oracle import metric as om
+    from vqvae_amd import _lib
+    from vqvae_amd._device import device
+    from vqvae_amd.geo.riemannian_metric import edge_lengths_graph_device
+    from vqvae_amd.spatial_decoder import DecoderExport, SpatialDecoder
+    dev = device()
+    n_nodes, n_edges, d = 70001, 600000, 16
+    sd = om.make_decoder_state(13, d, 1, norm_type="batch")
+    dec = SpatialDecoder(1, (256, 128, 64), d, 28, "batch")
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    dec = dec.to(dev).eval()
+    r = np.random.RandomState(5)
+    z = torch.from_numpy(r.randn(n_nodes, d).astype(np.float32)).to(dev)
+    src_h = r.randint(0, n_nodes, n_edges).astype(np.int32)
+    dst_h = (src_h + 1 + r.randint(0, n_nodes - 1, n_edges)).astype(np.int32) % n_nodes
+    src, dst = torch.from_numpy(src_h).to(dev), torch.from_numpy(dst_h).to(dev)
+    ex = DecoderExport(dec, dev)
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.geo_set_option(b"jvp_node_jacobian", 1))
+    _lib.check(lib.geo_set_option(b"jvp_node_jacobian", 0), "geo_set_option")
+    per_edge_end = edge_lengths_graph_device(ex, z, src, dst, 512).cpu().numpy()
+    _lib.check(lib.geo_set_option(b"jvp_node_jacobian", 2), "geo_set_option")
+    got = edge_lengths_graph_device(ex, z, src, dst, 512).cpu().numpy()
+    assert not np.array_equal(got, per_edge_end)
+    rel = np.abs(got - per_edge_end) / per_edge_end
+    assert np.quantile(rel, 0.99) < 2e-6 and rel.max() < 1e-4, (np.quantile(rel, 0.99), rel.max())
+
+
+@pytest.mark.gpu
 def test_per_latent_jacobian_route_is_not_taken_where_it_does_not_apply(request):
     """Train-mode BatchNorm (the statistics are the batch's), d > 16, and graphs with few edges per latent keep the per-edge-end
     path: same bits with the option on (1, 2) and off."""
