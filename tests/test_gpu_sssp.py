@@ -281,15 +281,16 @@ def test_device_kpp_chain_at_large_n_equals_host_draw(n):
     from vqvae_amd.geo.kmeans_optimized import fit_kmedoids_optimized
     from vqvae_amd.geo.knn_graph_optimized import knn_graph_device
     G, _, _ = knn_graph_device(torch.from_numpy(latents(n, 8, 5)).to(device()), 8, mode="distance", sym="union")
-    med_d, assign_d, qe_d = fit_kmedoids_optimized(G, K=48, init="kpp", seed=11)
+    K = 160                                                      # (~2 % of the approximate draws decline: the exact draw runs too)
+    med_d, assign_d, qe_d = fit_kmedoids_optimized(G, K=K, init="kpp", seed=11)
     os.environ["GEO_KPP_HOST_DRAW"] = "1"
     try:
-        med_h, assign_h, qe_h = fit_kmedoids_optimized(G, K=48, init="kpp", seed=11)
+        med_h, assign_h, qe_h = fit_kmedoids_optimized(G, K=K, init="kpp", seed=11)
     finally:
         os.environ.pop("GEO_KPP_HOST_DRAW")
     np.testing.assert_array_equal(med_d, med_h)
     np.testing.assert_array_equal(assign_d, assign_h)
-    assert qe_d == qe_h and len(set(med_d.tolist())) == 48
+    assert qe_d == qe_h and len(set(med_d.tolist())) == K
 
 
 def test_kpp_small_and_degenerate_graphs():
